@@ -1,0 +1,49 @@
+"""Helpers shared by the oracle and the GPU parity tests: load a golden fixture and rebuild its weights."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ref_cpu as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TINY_QWEN3 = R.LMConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=2, head_dim=128)
+TINY_LLAMA = R.LMConfig(vocab_size=1031, hidden_size=256, intermediate_size=768, num_hidden_layers=2,
+                        num_attention_heads=4, num_key_value_heads=4, head_dim=64, rms_norm_eps=1e-6,
+                        rope_theta=10000.0, tie_word_embeddings=False, qk_norm=False)
+CASES = {"tiny_qwen3": TINY_QWEN3, "tiny_llama": TINY_LLAMA}
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def tiny_params(cfg):
+    """Same recipe as tools/make_golden.py: seed-0 init, norm gains perturbed with seed 7."""
+    params = R.init_params(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    for k in params:
+        if "norm" in k:
+            params[k] = 1.0 + 0.1 * torch.randn(params[k].shape, generator=g)
+    return params
+
+
+def checksum(params):
+    return float(sum(v.double().abs().sum() for v in params.values()))
+
+
+def slim(a):
+    a = np.asarray(a)
+    if a.ndim == 2 and a.size > 65536:
+        return a[::4]
+    if a.ndim == 3:
+        return a[:, ::4, :]
+    return a
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

@@ -1,0 +1,247 @@
+"""Generate golden fixtures under tests/golden/ from the stock `transformers` modules the reference builds.
+
+Run ONLY in the build container (needs `transformers`; never runs on the GPU box, never imported by the
+product). The reference constructs its networks with AutoModelForCausalLM.from_config / GPT2LMHeadModel
+(/root/reference/src/model/model.py:65,136), i.e. the stock transformers classes; this script instantiates the
+same classes from explicit configs, runs them on seeded synthetic token batches and stores inputs + outputs.
+
+    python tools/make_golden.py            # writes tests/golden/*.npz
+
+Weights are NOT stored: they are re-created from a seed with oracle.ref_cpu.init_params (torch CPU generator,
+deterministic for a fixed torch build), and a checksum of them is stored so that a drift would be noticed.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_cpu as R  # noqa: E402
+
+import transformers  # noqa: E402
+from transformers import Qwen3Config, Qwen3ForCausalLM, LlamaConfig, LlamaForCausalLM  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def hf_qwen3(cfg: R.LMConfig, params):
+    hc = Qwen3Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                     num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                     num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                     max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+                     tie_word_embeddings=cfg.tie_word_embeddings,
+                     rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta},
+                     bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
+    m = Qwen3ForCausalLM(hc)
+    missing, unexpected = m.load_state_dict(params, strict=False)
+    assert not unexpected, unexpected
+    assert all(k == "lm_head.weight" for k in missing), missing
+    m.tie_weights()
+    return m.train()
+
+
+def hf_llama(cfg: R.LMConfig, params):
+    hc = LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                     num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                     num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                     max_position_embeddings=cfg.max_position_embeddings, rms_norm_eps=cfg.rms_norm_eps,
+                     tie_word_embeddings=cfg.tie_word_embeddings,
+                     rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta},
+                     bos_token_id=cfg.bos_token_id, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
+    m = LlamaForCausalLM(hc)
+    missing, unexpected = m.load_state_dict(params, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return m.train()
+
+
+def slim(a):
+    """Big 2-D tensors keep every 4th row, logits [B,S,V] every 4th position (tests apply the same slicing)."""
+    a = np.asarray(a)
+    if a.ndim == 2 and a.size > 65536:
+        return a[::4]
+    if a.ndim == 3:
+        return a[:, ::4, :]
+    return a
+
+
+def checksum(params):
+    return float(sum(v.double().abs().sum() for v in params.values()))
+
+
+def grads_of(m):
+    return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+GRAD_KEYS = ["model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight",
+             "model.layers.0.self_attn.k_proj.weight", "model.layers.0.self_attn.v_proj.weight",
+             "model.layers.0.self_attn.o_proj.weight", "model.layers.0.input_layernorm.weight",
+             "model.layers.0.post_attention_layernorm.weight", "model.layers.0.mlp.gate_proj.weight",
+             "model.layers.0.mlp.up_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.norm.weight"]
+
+
+def tiny_case(name, cfg, builder, seed_ids=1234, B=2, S=128, extra_keys=()):
+    params = R.init_params(cfg, seed=0)
+    # make norm gains non-trivial so that their role is exercised
+    g = torch.Generator().manual_seed(7)
+    for k in params:
+        if "norm" in k:
+            params[k] = 1.0 + 0.1 * torch.randn(params[k].shape, generator=g)
+    m = builder(cfg, params)
+    gen = torch.Generator().manual_seed(seed_ids)
+    ids = torch.randint(3, cfg.vocab_size, (B, S), generator=gen)
+    out = {"seed_params": 0, "seed_norm": 7, "seed_ids": seed_ids, "param_checksum": checksum(params),
+           "input_ids": ids.numpy()}
+
+    # ---- fp32, labels = ids, no mask
+    m.zero_grad()
+    o = m(input_ids=ids, labels=ids)
+    o.loss.backward()
+    out["fp32_loss"] = o.loss.item()
+    out["fp32_logits"] = o.logits.detach().numpy()
+    gr = grads_of(m)
+    for k in list(GRAD_KEYS) + list(extra_keys):
+        if k in gr:
+            out["fp32_grad/" + k] = gr[k].numpy()
+    gnorm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g_) for g_ in gr.values()]))
+    out["fp32_grad_norm"] = gnorm.item()
+
+    # ---- one clip(1.0)+AdamW step at lr schedule step 0 and step `warmup`
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-5, weight_decay=0.1, betas=(0.9, 0.95), eps=1e-5)
+    warm = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1e-6, end_factor=1.0, total_iters=10)
+    dec = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.1, total_iters=12 * 20 - 10)
+    sch = torch.optim.lr_scheduler.SequentialLR(opt, [warm, dec], milestones=[10])
+    lrs = []
+    losses = []
+    for step in range(14):
+        m.zero_grad()
+        o = m(input_ids=ids, labels=ids)
+        o.loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+        losses.append(o.loss.item())
+    out["train_lrs"] = np.array(lrs)
+    out["train_losses"] = np.array(losses)
+    sd = m.state_dict()
+    for k in GRAD_KEYS[:2] + GRAD_KEYS[-1:]:
+        out["after14/" + k] = sd[k].detach().numpy().copy()
+
+    # ---- restore, padded batch (right padding, labels -100 on pads), fp32
+    m = builder(cfg, params)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, S - 37:] = 0
+    lab = ids.clone()
+    lab[mask == 0] = -100
+    lab[0, :11] = -100  # prompt-span masking as in train_aria.py:139-140
+    m.zero_grad()
+    o = m(input_ids=ids, attention_mask=mask, labels=lab)
+    o.loss.backward()
+    out["pad_mask"] = mask.numpy()
+    out["pad_labels"] = lab.numpy()
+    out["pad_loss"] = o.loss.item()
+    out["pad_logits"] = o.logits.detach().numpy()
+    gr = grads_of(m)
+    out["pad_grad/" + GRAD_KEYS[1]] = gr[GRAD_KEYS[1]].numpy()
+    out["pad_grad/" + GRAD_KEYS[0]] = gr[GRAD_KEYS[0]].numpy()
+
+    # ---- bf16 autocast (precision="bf16-mixed"), labels = ids
+    m.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o = m(input_ids=ids, labels=ids)
+    o.loss.backward()
+    out["bf16_loss"] = o.loss.item()
+    out["bf16_logits"] = o.logits.detach().float().numpy()
+    gr = grads_of(m)
+    for k in GRAD_KEYS:
+        if k in gr:
+            out["bf16_grad/" + k] = gr[k].float().numpy()
+
+    # ---- greedy decode, 512 tokens from an 8-token prompt, KV cache on, EOS disabled
+    m.eval()
+    prompt = ids[:1, :8]
+    with torch.no_grad():
+        gtok = m.generate(prompt, max_new_tokens=512, do_sample=False, eos_token_id=None, pad_token_id=0,
+                          use_cache=True)
+    out["greedy_tokens"] = gtok.numpy()
+    # teacher-forced logits margin for the greedy run (top1-top2 gap per step) for tie diagnostics
+    with torch.no_grad():
+        lg = m(input_ids=gtok[:, :-1]).logits[0, 7:, :]
+    top2 = torch.topk(lg, 2, dim=-1)[0]
+    out["greedy_margin"] = (top2[:, 0] - top2[:, 1]).numpy()
+
+    # ---- sampled decode with injected noise: multinomial(p,1) == argmax(p/q), q ~ Exp(1)
+    for tag, kw in (("t097_p095", dict(temperature=0.97, top_p=0.95)),
+                    ("t1_k5_p095", dict(temperature=1.0, top_k=5, top_p=0.95))):
+        steps, Bs = 64, 2
+        ng = torch.Generator().manual_seed(4321)
+        noise = torch.empty(steps, Bs, cfg.vocab_size).exponential_(1.0, generator=ng)
+        it = iter(range(steps))
+        orig = torch.multinomial
+
+        def fake_multinomial(probs, num_samples, replacement=False, *, generator=None):
+            t = next(it)
+            return (probs / noise[t]).argmax(dim=-1, keepdim=True)
+
+        torch.multinomial = fake_multinomial
+        try:
+            with torch.no_grad():
+                stok = m.generate(ids[:Bs, :8], max_new_tokens=steps, do_sample=True, eos_token_id=None,
+                                  pad_token_id=0, use_cache=True, **kw)
+        finally:
+            torch.multinomial = orig
+        out[f"sample_{tag}/tokens"] = stok.numpy()
+        out[f"sample_{tag}/noise_seed"] = 4321
+    m.train()
+
+    out = {k: slim(v) if isinstance(v, np.ndarray) and ("grad/" in k or "logits" in k or "after14/" in k) else v
+           for k, v in out.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "fp32 loss", out["fp32_loss"], "bf16 loss", out["bf16_loss"], "pad loss", out["pad_loss"])
+    return params, out
+
+
+def full_dq_case():
+    """C1 shape: default decoder, fp32, B=4, S=1024; scalars and slices only."""
+    cfg = R.LMConfig()
+    params = R.init_params(cfg, seed=0)
+    m = hf_qwen3(cfg, params)
+    gen = torch.Generator().manual_seed(1234)
+    ids = torch.randint(3, 30000, (4, 1024), generator=gen)
+    o = m(input_ids=ids, labels=ids)
+    o.loss.backward()
+    gr = grads_of(m)
+    out = {"param_checksum": checksum(params), "loss": o.loss.item(),
+           "logits_slice": o.logits[:, ::97, ::1013].detach().numpy(),
+           "grad_norm": torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g_) for g_ in gr.values()])).item(),
+           "grad_q0_slice": gr["model.layers.0.self_attn.q_proj.weight"][::16, ::16].numpy(),
+           "grad_down13_slice": gr["model.layers.13.mlp.down_proj.weight"][::16, ::16].numpy(),
+           "grad_norm_final": gr["model.norm.weight"].numpy(),
+           "grad_embed_rows": gr["model.embed_tokens.weight"][ids[0, :16]].numpy(),
+           "ids_head": ids[:, :16].numpy()}
+    m.eval()
+    with torch.no_grad():
+        gtok = m.generate(ids[:1, :8], max_new_tokens=256, do_sample=False, eos_token_id=None, pad_token_id=0)
+    out["greedy_tokens"] = gtok.numpy()
+    with torch.autocast("cpu", dtype=torch.bfloat16), torch.no_grad():
+        ob = m(input_ids=ids[:1, :256], labels=ids[:1, :256])
+    out["bf16_loss_b1s256"] = ob.loss.item()
+    np.savez_compressed(os.path.join(OUT, "dq_full_c1.npz"), **out)
+    print("dq_full_c1 loss", out["loss"], "gnorm", out["grad_norm"])
+
+
+if __name__ == "__main__":
+    print("transformers", transformers.__version__, "torch", torch.__version__)
+    tiny_q = R.LMConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=2, head_dim=128)
+    tiny_case("tiny_qwen3", tiny_q, hf_qwen3)
+    tiny_l = R.LMConfig(vocab_size=1031, hidden_size=256, intermediate_size=768, num_hidden_layers=2,
+                        num_attention_heads=4, num_key_value_heads=4, head_dim=64, rms_norm_eps=1e-6,
+                        rope_theta=10000.0, tie_word_embeddings=False, qk_norm=False)
+    tiny_case("tiny_llama", tiny_l, hf_llama, extra_keys=("lm_head.weight",))
+    if "--full" in sys.argv:
+        full_dq_case()
