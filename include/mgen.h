@@ -1,0 +1,125 @@
+/* libmgen_hip.so — C-ABI of the gfx950 (MI355X) kernels for the decoder-only MIDI language model hot path.
+ *
+ * The reference (xingjianll/symbolic-music-generation) has no FFI boundary of its own: its hot path is the Python
+ * call `model(input_ids, attention_mask, labels)` / `model.generate(...)` (src/model/model.py:142-149,
+ * src/test_tokenizer.py:129-136), whose arithmetic is executed by torch/transformers operators. Each entry point
+ * below replaces one such operator (or a fused group of them) and cites the reference-side call it stands for
+ * (TF = the `transformers` package the reference pins, files under transformers/).
+ *
+ * Conventions: every pointer is a DEVICE pointer unless said otherwise; sizes are element counts; "ld"/strides are in
+ * elements; `stream` is a hipStream_t. Every function returns 0 on success, a negative code otherwise
+ * (-1 invalid argument, -2 launch failure) and leaves a message for mgen_last_error() (thread local). No function
+ * allocates or frees device memory or synchronises the device. bf16 = IEEE bfloat16 stored as 16-bit words.
+ */
+#ifndef MGEN_H
+#define MGEN_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mgen_stream_t; /* hipStream_t */
+
+/* ---- runtime ------------------------------------------------------------------------------------------------ */
+const char* mgen_last_error(void);
+int mgen_version(void);
+/* name of the device's gfx architecture into name[name_len]; returns the CU count. */
+int mgen_device_info(int device, char* name, int name_len);
+
+/* ---- linear layers -------------------------------------------------------------------------------------------
+ * C[M,N] = alpha * op(A)[M,K] * op(B)[K,N], bf16 operands, fp32 accumulate on MFMA.
+ * Replaces nn.Linear forward (TF models/qwen3/modeling_qwen3.py:76-83,225-236: x @ W^T with W [out,in]:
+ * transA=0, transB=0), its input gradient (dY @ W: transB=1) and its weight gradient (dY^T @ X: transA=1, transB=1).
+ * transA=0: A stored [M][lda>=K8]; transA=1: A stored [K][lda>=M8] (reduction index is the row).
+ * transB=0: B stored [N][ldb>=K8]; transB=1: B stored [K][ldb>=N8]. (X8 = X rounded up to 8; padding columns of a
+ * k-contiguous operand must hold zeros.)
+ * out_mode: 0 bf16 store, 1 fp32 store, 2 fp32 accumulate (C += ...), 3 fp32 C = resid + float(bf16(acc))
+ * (residual add of a bf16 projection output, TF models/qwen3/modeling_qwen3.py:316,322), 4 fp32 C = resid + acc. */
+int mgen_gemm_bf16(const void* A, const void* B, void* C, const void* resid, int M, int N, int K, long lda, long ldb,
+                   long ldc, long ldr, int transA, int transB, int out_mode, float alpha, mgen_stream_t stream);
+
+/* ---- RMSNorm over the fp32 residual stream -------------------------------------------------------------------
+ * Qwen3RMSNorm.forward, reference src/model/modeling.py:60-65. y is bf16 (out_bf16=1) or fp32; rstd[T] is saved for
+ * the backward. d % 4 == 0, d <= 2048. */
+int mgen_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, long T, int d, float eps, int out_bf16,
+                     mgen_stream_t stream);
+/* autograd backward of the above: dres (fp32 [T,d]) = (accumulate ? dres : 0) + dx; optional copy of the updated dres
+ * in the dy dtype (dres_lp, may be null); dw[d] += sum_rows dy * x * rstd (atomic adds). */
+int mgen_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dres, void* dres_lp,
+                     float* dw, long T, int d, int accumulate, int dy_bf16, mgen_stream_t stream);
+
+/* ---- rotary embedding + per-head q/k RMSNorm -----------------------------------------------------------------
+ * cos_sin[npos][half_dim][2] = {cos, sin}(pos * inv_freq[i]) — Qwen3RotaryEmbedding.forward,
+ * TF models/qwen3/modeling_qwen3.py:126-137 (inv_freq computed by the caller as at :120-123). */
+int mgen_rope_table(const float* inv_freq, float* cos_sin, int npos, int half_dim, mgen_stream_t stream);
+/* q_norm/k_norm + apply_rotary_pos_emb (TF models/qwen3/modeling_qwen3.py:252-257, :140-170, split-half pairing) for
+ * the HQ query heads and HK key heads stored at the start of each row of qkv [T][ld_in]. wq/wk null = no norm
+ * (Llama-style block). pos[T] int32 or null (position = t % S). D = 64 or 128. qout/kout: [T][ld_q], [T][ld_k]. */
+int mgen_qknorm_rope_fwd(const void* qkv, long ld_in, void* qout, void* kout, long ld_q, long ld_k, const float* wq,
+                         const float* wk, const float* cos_sin, const int* pos, int S, long T, int HQ, int HK, int D,
+                         float eps, int is_bf16, mgen_stream_t stream);
+/* backward of the above; dqk holds d(out) for the q and k heads ([T][ld_in]); results go to dq_raw/dk_raw (may alias
+ * dqk); raw_qkv is the forward input; dwq/dwk[D] += gain gradients. */
+int mgen_qknorm_rope_bwd(const void* dqk, long ld_in, void* dq_raw, void* dk_raw, long ld_q, long ld_k,
+                         const void* raw_qkv, long ld_raw, const float* wq, const float* wk, float* dwq, float* dwk,
+                         const float* cos_sin, const int* pos, int S, long T, int HQ, int HK, int D, float eps,
+                         int is_bf16, mgen_stream_t stream);
+
+/* ---- causal self-attention (bf16 MFMA, head_dim 128) ---------------------------------------------------------
+ * scaled_dot_product_attention(is_causal=True, scale) — TF integrations/sdpa_attention.py:154-163, eager twin
+ * TF models/qwen3/modeling_qwen3.py:185-207. q/k/v/out are token-major [B*S][heads][128] views with token strides
+ * sq/sk/sv/so; lse [B][H][S] fp32 (natural log) is saved for the backward. */
+int mgen_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, long sq, long sk, long sv,
+                  long so, int B, int S, int H, int KVH, int head_dim, float scale, mgen_stream_t stream);
+/* autograd backward: dq/dk/dv (bf16) from dout; delta [B][H][S] fp32 is caller-provided scratch. */
+int mgen_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                  float* delta, void* dq, void* dk, void* dv, long sq, long sk, long sv, long so, long sdo, long sdq,
+                  long sdk, long sdv, int B, int S, int H, int KVH, int head_dim, float scale, mgen_stream_t stream);
+
+/* ---- SwiGLU gate ---------------------------------------------------------------------------------------------
+ * act = silu(gate) * up with gu = [gate | up] per row ([T][2I] bf16) — Qwen3MLP.forward,
+ * TF models/qwen3/modeling_qwen3.py:81-83. round_silu=1 rounds silu(gate) to bf16 first (autocast behaviour). */
+int mgen_swiglu_fwd(const void* gu, void* act, long T, int I, int round_silu, mgen_stream_t stream);
+int mgen_swiglu_bwd(const void* gu, const void* dact, void* dgu, long T, int I, mgen_stream_t stream);
+
+/* ---- token embedding -----------------------------------------------------------------------------------------
+ * nn.Embedding gather (TF models/qwen3/modeling_qwen3.py:352,381) and its index_add backward. ids int64 [T].
+ * *err_flag (int, may be null) is set to 1 when an id is outside [0, V). */
+int mgen_embedding_fwd(const long* ids, const float* table, float* out, long T, int d, long V, int* err_flag,
+                       mgen_stream_t stream);
+int mgen_embedding_bwd(const long* ids, const float* dout, float* dtable, long T, int d, long V, mgen_stream_t stream);
+
+/* dtype conversion: kind 0 fp32 -> bf16, 1 bf16 -> fp32. */
+int mgen_cast(const void* in, void* out, long n, int kind, mgen_stream_t stream);
+
+/* ---- shifted cross entropy (ForCausalLMLoss, TF loss/loss_utils.py:49-71) -----------------------------------
+ * labels int64 [B][S]; row (b,s) is scored against labels[b][s+1]. */
+int mgen_ce_count(const long* labels, long B, int S, long ignore_index, float* inv_count, int* count,
+                  mgen_stream_t stream);
+/* rows `tok0 .. tok0+rows` of the flattened [B*S] token axis; logits [rows][ld] (bf16 or fp32) are replaced in place
+ * by d(loss)/d(logits) when write_grad; row_loss[B*S] and lse_out[B*S] (may be null) are indexed by token. */
+int mgen_ce_fwd_bwd(void* logits, const long* labels, long tok0, long rows, int V, long ld, int S, long ignore_index,
+                    const float* inv_count, float grad_scale, float* row_loss, float* lse_out, int write_grad,
+                    int is_bf16, mgen_stream_t stream);
+int mgen_ce_finalize(const float* row_loss, long T, const float* inv_count, float* loss, mgen_stream_t stream);
+
+/* ---- optimizer -----------------------------------------------------------------------------------------------
+ * clip_grad_norm_ (reference src/train.py:66): out[0] = ||grad||_2, out[1] = min(1, max_norm/(norm+1e-6)).
+ * workspace: mgen_sumsq_partial_count() doubles. */
+int mgen_sumsq_partial_count(void);
+int mgen_grad_norm_clip(const float* grad, long n, float max_norm, double* workspace, float* out,
+                        mgen_stream_t stream);
+/* torch.optim.AdamW step (reference src/model/model.py:19-25) over n flat fp32 elements; grad is scaled by clip[1]
+ * when clip is given; shadow_bf16 (may be null) receives the rounded new parameters. step is 1-based. */
+int mgen_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
+                    const float* clip, float lr, float beta1, float beta2, float eps, float wd, long step,
+                    mgen_stream_t stream);
+int mgen_scale_f32(float* x, long n, float s, mgen_stream_t stream);
+/* y += a * (*a_dev) * x ; x *= a * (*a_dev)  (a_dev may be null): the upstream loss gradient stays on the device. */
+int mgen_axpy_f32(float* y, const float* x, long n, float a, const float* a_dev, mgen_stream_t stream);
+int mgen_scale_bf16(void* x, long n, float a, const float* a_dev, mgen_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGEN_H */

@@ -1,0 +1,159 @@
+// Shifted-label cross entropy over a chunk of logits rows, forward and backward in one pass (HBM-bound).
+//
+// Reference: ForCausalLMLoss, transformers loss/loss_utils.py:49-71 — logits.float(); labels padded right with -100 and
+// shifted by one; cross_entropy(mean over labels != ignore_index). Row t = (b, s) is scored against labels[b, s+1]
+// (ignored when s is the last position or the label equals ignore_index).
+//
+// One 256-thread block per row: pass 1 computes the row's max and sum of exponentials with 16-byte loads, pass 2
+// overwrites the logits in place with d(loss)/d(logits) = (softmax - onehot) * grad_scale / n_valid in the same dtype
+// (what the lm_head dgrad/wgrad GEMMs then read), and the row's loss term goes to row_loss[t] (0 for ignored rows).
+// The mean is taken by mgen_ce_finalize in a fixed order, so the loss is bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <typename LT> struct Row8;
+template <> struct Row8<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&x)[8]) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&x)[8]) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)x[e];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+template <> struct Row8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&x)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = a[e]; x[4 + e] = b[e]; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&x)[8]) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{x[0], x[1], x[2], x[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{x[4], x[5], x[6], x[7]};
+    }
+};
+
+__global__ void ce_count_kernel(const long* __restrict__ labels, long B, int S, long ignore_index,
+                                float* __restrict__ inv_count, int* __restrict__ count) {
+    __shared__ float red[4];
+    float c = 0.f;
+    const long n = B * S;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const int s = (int)(i % S);
+        if (s + 1 < S && labels[i + 1] != ignore_index) c += 1.f;
+    }
+    c = block_sum_256(c, red);
+    if (threadIdx.x == 0) {
+        *inv_count = 1.f / c;  // n_valid == 0 gives inf and the mean becomes NaN, as in the reference
+        if (count) *count = (int)c;
+    }
+}
+
+template <typename LT, bool WRITE_GRAD>
+__global__ __launch_bounds__(256) void ce_kernel(LT* __restrict__ logits, const long* __restrict__ labels, long tok0,
+                                                 int V, long ld, int S, long ignore_index,
+                                                 const float* __restrict__ inv_count, float grad_scale,
+                                                 float* __restrict__ row_loss, float* __restrict__ lse_out) {
+    __shared__ float red[4];
+    const long r = blockIdx.x;
+    const long t = tok0 + r;
+    const int s = (int)(t % S);
+    long label = ignore_index;
+    if (s + 1 < S) label = labels[t + 1];
+    const bool valid = label != ignore_index && label >= 0 && label < V;
+    LT* row = logits + r * ld;
+    const int nvec = (V + 7) / 8;
+
+    float m = -1.0e30f, sum = 0.f;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+        float x[8];
+        Row8<LT>::load(row + i * 8, x);
+        float mx = m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            x[e] = (i * 8 + e < V) ? x[e] * LOG2E : -1.0e30f;
+            mx = fmaxf(mx, x[e]);
+        }
+        float acc = sum * __builtin_amdgcn_exp2f(m - mx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(x[e] - mx);
+        sum = acc;
+        m = mx;
+    }
+    const float M = block_max_256(m, red);
+    sum = block_sum_256(sum * __builtin_amdgcn_exp2f(m - M), red);
+    const float lse = (M + __log2f(sum)) * LN2;
+    if (threadIdx.x == 0) {
+        if (lse_out) lse_out[t] = lse;
+        row_loss[t] = valid ? (lse - (float)row[label]) : 0.f;
+    }
+    if (!WRITE_GRAD) return;
+    __syncthreads();  // row[label] is read above before anyone overwrites the row
+    const float g = valid ? grad_scale * (*inv_count) : 0.f;
+    const float inv_sum = 1.f / sum;
+    for (int i = threadIdx.x; i < nvec; i += 256) {
+        float x[8];
+        Row8<LT>::load(row + i * 8, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = i * 8 + e;
+            float p = __builtin_amdgcn_exp2f(x[e] * LOG2E - M) * inv_sum;
+            if (idx == label) p -= 1.f;
+            x[e] = idx < V ? p * g : 0.f;
+        }
+        Row8<LT>::store(row + i * 8, x);
+    }
+}
+
+__global__ void ce_finalize_kernel(const float* __restrict__ row_loss, long T, const float* __restrict__ inv_count,
+                                   float* __restrict__ loss) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < T; i += 256) acc += (double)row_loss[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * (double)(*inv_count));
+}
+
+}  // namespace
+
+extern "C" int mgen_ce_count(const long* labels, long B, int S, long ignore_index, float* inv_count, int* count,
+                             hipStream_t stream) {
+    MGEN_REQUIRE(labels && inv_count && B > 0 && S > 0, "mgen_ce_count: bad arguments");
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, stream, labels, B, S, ignore_index, inv_count, count);
+    return mgen_check_launch("mgen_ce_count");
+}
+
+extern "C" int mgen_ce_fwd_bwd(void* logits, const long* labels, long tok0, long rows, int V, long ld, int S,
+                               long ignore_index, const float* inv_count, float grad_scale, float* row_loss,
+                               float* lse_out, int write_grad, int is_bf16, hipStream_t stream) {
+    MGEN_REQUIRE(logits && labels && inv_count && row_loss, "mgen_ce_fwd_bwd: null pointer");
+    MGEN_REQUIRE(rows > 0 && V > 0 && S > 0 && ld >= ((V + 7) / 8) * 8 && ld % 8 == 0,
+                 "mgen_ce_fwd_bwd: need ld %% 8 == 0 and ld >= V rounded up to 8 (V=%d ld=%ld)", V, ld);
+    const dim3 grid((unsigned)rows), block(256);
+#define CE_LAUNCH(TT, WG)                                                                                          \
+    hipLaunchKernelGGL((ce_kernel<TT, WG>), grid, block, 0, stream, (TT*)logits, labels, tok0, V, ld, S, ignore_index, \
+                       inv_count, grad_scale, row_loss, lse_out)
+    if (is_bf16) { if (write_grad) CE_LAUNCH(bf16, true); else CE_LAUNCH(bf16, false); }
+    else { if (write_grad) CE_LAUNCH(float, true); else CE_LAUNCH(float, false); }
+#undef CE_LAUNCH
+    return mgen_check_launch("mgen_ce_fwd_bwd");
+}
+
+extern "C" int mgen_ce_finalize(const float* row_loss, long T, const float* inv_count, float* loss, hipStream_t stream) {
+    MGEN_REQUIRE(row_loss && inv_count && loss && T > 0, "mgen_ce_finalize: bad arguments");
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, stream, row_loss, T, inv_count, loss);
+    return mgen_check_launch("mgen_ce_finalize");
+}

@@ -1,0 +1,236 @@
+// bf16 MFMA GEMM for gfx950: C[M,N] = op(A)[M,K] * op(B)[K,N], fp32 accumulate.
+//
+// Serves the linear layers of the decoder on the training and prefill paths
+// (reference: nn.Linear calls in transformers models/qwen3/modeling_qwen3.py:76-83,225-236 and their autograd
+// backward): forward x*W^T (A k-contiguous, B k-contiguous), dgrad dY*W (B stored [K][N]), wgrad dY^T*X (both
+// operands stored with the reduction index as the row index).
+//
+// Tiling: 256 threads = 4 waves, block tile 128x128, K step 64, each wave a 64x64 sub-tile as 2x2
+// v_mfma_f32_32x32x16_bf16 tiles. Operand tiles are staged global -> registers -> LDS (16-byte vectors, zero
+// filled out of range) into two LDS buffers, one barrier per K step; the next tile's global loads are issued
+// before the MFMAs of the current one. An operand whose reduction index is contiguous in memory lives in LDS as
+// [128 rows][64 k] (row reads); one whose reduction index is the row index lives as [64 k][128 cols] and is read
+// with the transposing LDS read, so no transposed copy of activations or weights is ever made in HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+enum OutMode { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_F32_RESID_BF16ROUND = 3, OUT_F32_RESID = 4 };
+
+struct GemmArgs {
+    const bf16* A;
+    const bf16* B;
+    void* C;
+    const float* R;  // residual for the OUT_F32_RESID* modes
+    int M, N, K;
+    long lda, ldb, ldc, ldr;
+    float alpha;
+    int nbm, nbn;
+};
+
+// ---- global -> register staging of one operand tile (4 x 16 bytes per thread) -----------------------------
+// KC: operand stored [rows][K] (k contiguous): tile = 128 rows x 64 k
+// MC: operand stored [K][cols] (reduction index is the row): tile = 64 k x 128 cols
+template <bool MC>
+__device__ __forceinline__ void load_tile(u32x4 (&st)[4], const bf16* __restrict__ P, long ld, int row0, int k0,
+                                          int nrows, int K, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (!MC) {
+            const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+            const int gr = row0 + row, gk = k0 + ch * 8;
+            if (gr < nrows && gk < K) v = *reinterpret_cast<const u32x4*>(P + (long)gr * ld + gk);
+        } else {
+            const int kr = (tid >> 4) + 16 * i, ch = tid & 15;
+            const int gk = k0 + kr, gc = row0 + ch * 8;
+            if (gk < K && gc < nrows) v = *reinterpret_cast<const u32x4*>(P + (long)gk * ld + gc);
+        }
+        st[i] = v;
+    }
+}
+
+template <bool MC>
+__device__ __forceinline__ void store_tile(const u32x4 (&st)[4], char* lds, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!MC) {
+            const int row = (tid >> 3) + 32 * i, ch = tid & 7;
+            lds_write_b128(lds, img128_off(row, ch), st[i]);
+        } else {
+            const int kr = (tid >> 4) + 16 * i, ch = tid & 15;
+            lds_write_b128(lds, img256_off(kr, ch), st[i]);
+        }
+    }
+}
+
+// fragment for output rows/cols [o0, o0+32) and k-step ks (16 reduction indices) of the current tile
+template <bool MC>
+__device__ __forceinline__ bf16x8 load_frag(const char* tile, int o0, int ks, int lane) {
+    if (!MC) return frag_row_img128(tile, o0, ks, lane);
+    return frag_col_img256<false>(tile, 16 * ks, o0, lane);
+}
+
+template <bool TA, bool TB, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // buffer b: A tile at smem + b*2*TILE_BYTES, B tile right behind it
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware, grouped tile order: 8 row-tiles share the sweep over the column tiles
+    const int nwg = g.nbm * g.nbn;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    constexpr int GROUP = 8;
+    const int width = GROUP * g.nbn;
+    const int grp = wg / width;
+    const int first_m = grp * GROUP;
+    const int gsz = min(g.nbm - first_m, GROUP);
+    const int tm = first_m + (wg % width) % gsz;
+    const int tn = (wg % width) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 sa[4], sb[4];
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile<TA>(sa, g.A, g.lda, m0, 0, g.M, g.K, tid);
+    load_tile<TB>(sb, g.B, g.ldb, n0, 0, g.N, g.K, tid);
+    store_tile<TA>(sa, smem, tid);
+    store_tile<TB>(sb, smem + TILE_BYTES, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile<TA>(sa, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
+            load_tile<TB>(sb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+        }
+        const char* ta = smem + cur * 2 * TILE_BYTES;
+        const char* tb = ta + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = load_frag<TA>(ta, wm + 32 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = load_frag<TB>(tb, wn + 32 * j, ks, lane);
+            // D[row = n][col = m]: the B-side fragment is the MFMA's A operand, so that each lane ends up with
+            // 4 consecutive n of one output row m (vector stores along the contiguous dimension of C).
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
+        }
+        if (kt + 1 < nk) {
+            char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            store_tile<TA>(sa, na, tid);
+            store_tile<TB>(sb, na + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, per tile, m = lane&31 and n = 8*g4 + 4*(lane>>5) + e (g4 = 0..3, e = 0..3)
+    const int h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm + 32 * i + (lane & 31);
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + wn + 32 * j + 8 * g4 + 4 * h;
+                if (n >= g.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e] * g.alpha;
+                const bool full = (n + 3 < g.N);
+                if (MODE == OUT_BF16) {
+                    bf16* c = reinterpret_cast<bf16*>(g.C) + (long)m * g.ldc + n;
+                    if (full && ((g.ldc & 3) == 0)) {
+                        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                        *reinterpret_cast<bf16x4*>(c) = o;
+                    } else {
+                        for (int e = 0; e < 4 && n + e < g.N; ++e) c[e] = (bf16)v[e];
+                    }
+                } else {
+                    float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n;
+                    if (MODE == OUT_F32_RESID_BF16ROUND || MODE == OUT_F32_RESID) {
+                        const float* r = g.R + (long)m * g.ldr + n;
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < g.N)
+                                v[e] = r[e] + (MODE == OUT_F32_RESID_BF16ROUND ? round_bf(v[e]) : v[e]);
+                    } else if (MODE == OUT_F32_ACC) {
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < g.N) v[e] += c[e];
+                    }
+                    if (full && ((g.ldc & 3) == 0)) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(c) = o;
+                    } else {
+                        for (int e = 0; e < 4 && n + e < g.N; ++e) c[e] = v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <bool TA, bool TB>
+int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
+    const dim3 grid(g.nbm * g.nbn), block(256);
+    const size_t lds = 4 * TILE_BYTES;
+    switch (mode) {
+        case OUT_BF16: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_BF16>), grid, block, lds, s, g); break;
+        case OUT_F32: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32>), grid, block, lds, s, g); break;
+        case OUT_F32_ACC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ACC>), grid, block, lds, s, g); break;
+        case OUT_F32_RESID_BF16ROUND:
+            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID_BF16ROUND>), grid, block, lds, s, g);
+            break;
+        case OUT_F32_RESID: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID>), grid, block, lds, s, g); break;
+        default: mgen_set_error("mgen_gemm_bf16: unknown out_mode %d", mode); return MGEN_EINVAL;
+    }
+    return mgen_check_launch("mgen_gemm_bf16");
+}
+
+}  // namespace
+
+extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void* resid, int M, int N, int K,
+                              long lda, long ldb, long ldc, long ldr, int transA, int transB, int out_mode,
+                              float alpha, hipStream_t stream) {
+    MGEN_REQUIRE(A && B && C, "mgen_gemm_bf16: null operand");
+    MGEN_REQUIRE(M > 0 && N > 0 && K > 0, "mgen_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    MGEN_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "mgen_gemm_bf16: lda/ldb must be multiples of 8 elements");
+    MGEN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+                 "mgen_gemm_bf16: operands must be 16-byte aligned");
+    // A k-contiguous operand is read in 8-element vectors along K: when K is not a multiple of 8 the row must be
+    // allocated up to the next multiple and the extra columns must hold zeros. A transposed operand is read in
+    // 8-element vectors along its output index (rows beyond K are never touched).
+    const int K8 = (K + 7) / 8 * 8;
+    if (!transA) MGEN_REQUIRE(lda >= K8, "mgen_gemm_bf16: A [M,K] needs lda >= K rounded up to 8");
+    else MGEN_REQUIRE(lda >= ((M + 7) / 8) * 8, "mgen_gemm_bf16: A [K,M] needs lda >= M rounded up to 8");
+    if (!transB) MGEN_REQUIRE(ldb >= K8, "mgen_gemm_bf16: B [N,K] needs ldb >= K rounded up to 8");
+    else MGEN_REQUIRE(ldb >= ((N + 7) / 8) * 8, "mgen_gemm_bf16: B [K,N] needs ldb >= N rounded up to 8");
+    MGEN_REQUIRE(ldc >= N, "mgen_gemm_bf16: ldc < N");
+    if (out_mode == OUT_F32_RESID_BF16ROUND || out_mode == OUT_F32_RESID)
+        MGEN_REQUIRE(resid != nullptr && ldr >= N, "mgen_gemm_bf16: residual mode needs resid and ldr>=N");
+    GemmArgs g;
+    g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.R = (const float*)resid;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
+    g.nbm = (M + BM - 1) / BM; g.nbn = (N + BN - 1) / BN;
+    MGEN_REQUIRE((long)g.nbm * g.nbn < (1L << 31), "mgen_gemm_bf16: grid too large");
+    if (!transA && !transB) return launch_mode<false, false>(g, out_mode, stream);
+    if (!transA && transB) return launch_mode<false, true>(g, out_mode, stream);
+    if (transA && !transB) return launch_mode<true, false>(g, out_mode, stream);
+    return launch_mode<true, true>(g, out_mode, stream);
+}

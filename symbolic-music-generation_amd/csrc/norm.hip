@@ -1,0 +1,173 @@
+// RMSNorm over the fp32 residual stream, forward and backward (HBM-bound, one wave per row, 16-byte accesses).
+//
+// Reference: Qwen3RMSNorm.forward, /root/reference/src/model/modeling.py:60-65
+//   y = w * (x.float() * rsqrt(mean(x^2) + eps)).to(x.dtype)
+// The residual stream is fp32 under the reference's bf16-mixed precision, so x is fp32 here; y is written in the
+// dtype the consuming GEMM reads (bf16: the rounding autocast applies at the GEMM input; fp32: parity mode).
+//
+// Backward (autograd of the above), with xh = x * rstd and g = dy * w:
+//   dx = rstd * (g - xh * mean(g * xh)),   dw = sum_rows dy * xh
+// dx is added into the fp32 gradient of the residual stream (the norm sits on a residual branch) and the updated
+// gradient is also emitted in the GEMM input dtype for the next dgrad/wgrad.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Vec4<bf16> {
+    static __device__ __forceinline__ f32x4 load(const bf16* p) {
+        bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
+        bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+        *reinterpret_cast<bf16x4*>(p) = o;
+    }
+};
+
+// VPL = float4 vectors per lane; a row has d <= 256*VPL elements, d % 4 == 0
+template <int VPL, typename OutT>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          OutT* __restrict__ y, float* __restrict__ rstd_out,
+                                                          long T, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    f32x4 wv[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        wv[i] = c < d ? Vec4<float>::load(w + c) : f32x4{0, 0, 0, 0};
+    }
+    for (long row = wave0; row < T; row += nwaves) {
+        const float* xr = x + row * d;
+        f32x4 xv[VPL];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            xv[i] = c < d ? Vec4<float>::load(xr + c) : f32x4{0, 0, 0, 0};
+            ss += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
+        }
+        ss = wave_sum(ss);
+        const float r = rsqrtf(ss / (float)d + eps);
+        if (lane == 0 && rstd_out) rstd_out[row] = r;
+        OutT* yr = y + row * d;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < d) Vec4<OutT>::store(yr + c, wv[i] * (xv[i] * r));
+        }
+    }
+}
+
+template <int VPL, typename DyT>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ rstd, float* __restrict__ dres,
+                                                          DyT* __restrict__ dres_lp, float* __restrict__ dw,
+                                                          long T, int d, int accumulate) {
+    __shared__ float red[4 * 256 * 4];  // per-wave dw partials for one 256-lane-vector slab
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wave0 = (long)blockIdx.x * 4 + wave;
+    const long nwaves = (long)gridDim.x * 4;
+    f32x4 wv[VPL], dwv[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        wv[i] = c < d ? Vec4<float>::load(w + c) : f32x4{0, 0, 0, 0};
+        dwv[i] = f32x4{0, 0, 0, 0};
+    }
+    for (long row = wave0; row < T; row += nwaves) {
+        const float r = rstd[row];
+        f32x4 xh[VPL], gv[VPL];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < d) {
+                xh[i] = Vec4<float>::load(x + row * d + c) * r;
+                const f32x4 dyv = Vec4<DyT>::load(dy + row * d + c);
+                gv[i] = dyv * wv[i];
+                dwv[i] += dyv * xh[i];
+                dot += gv[i][0] * xh[i][0] + gv[i][1] * xh[i][1] + gv[i][2] * xh[i][2] + gv[i][3] * xh[i][3];
+            } else {
+                xh[i] = f32x4{0, 0, 0, 0};
+                gv[i] = f32x4{0, 0, 0, 0};
+            }
+        }
+        dot = wave_sum(dot) / (float)d;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < d) {
+                f32x4 dx = (gv[i] - xh[i] * dot) * r;
+                float* p = dres + row * d + c;
+                if (accumulate) dx += Vec4<float>::load(p);
+                Vec4<float>::store(p, dx);
+                if (dres_lp) Vec4<DyT>::store(dres_lp + row * d + c, dx);
+            }
+        }
+    }
+    // dw: sum the 4 waves of the block through LDS, then one atomic per element per block
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = dwv[i];
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 s = *reinterpret_cast<f32x4*>(&red[lane * 4]);
+            for (int k = 1; k < 4; ++k) s += *reinterpret_cast<f32x4*>(&red[(k * 64 + lane) * 4]);
+            const int c = (i * 64 + lane) * 4;
+            if (c < d)
+                for (int e = 0; e < 4; ++e) atomicAdd(dw + c + e, s[e]);
+        }
+    }
+}
+
+inline int norm_grid(long T) {
+    long b = (T + 3) / 4;
+    return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+
+}  // namespace
+
+#define DISPATCH_VPL(d, CALL)                                                             \
+    if ((d) <= 512) { constexpr int VPL = 2; CALL; }                                      \
+    else { constexpr int VPL = 8; CALL; }
+
+extern "C" int mgen_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, long T, int d, float eps,
+                                int out_bf16, hipStream_t stream) {
+    MGEN_REQUIRE(x && w && y, "mgen_rmsnorm_fwd: null pointer");
+    MGEN_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && d <= 2048, "mgen_rmsnorm_fwd: need 0<d<=2048, d%%4==0 (d=%d)", d);
+    const dim3 grid(norm_grid(T)), block(256);
+    DISPATCH_VPL(d, {
+        if (out_bf16)
+            hipLaunchKernelGGL((rmsnorm_fwd_kernel<VPL, bf16>), grid, block, 0, stream, x, w, (bf16*)y, rstd, T, d, eps);
+        else
+            hipLaunchKernelGGL((rmsnorm_fwd_kernel<VPL, float>), grid, block, 0, stream, x, w, (float*)y, rstd, T, d, eps);
+    });
+    return mgen_check_launch("mgen_rmsnorm_fwd");
+}
+
+extern "C" int mgen_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dres,
+                                void* dres_lp, float* dw, long T, int d, int accumulate, int dy_bf16,
+                                hipStream_t stream) {
+    MGEN_REQUIRE(dy && x && w && rstd && dres && dw, "mgen_rmsnorm_bwd: null pointer");
+    MGEN_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && d <= 2048, "mgen_rmsnorm_bwd: need 0<d<=2048, d%%4==0 (d=%d)", d);
+    long b = (T + 3) / 4;
+    const dim3 grid((int)(b < 1024 ? b : 1024)), block(256);
+    DISPATCH_VPL(d, {
+        if (dy_bf16)
+            hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, bf16>), grid, block, 0, stream, (const bf16*)dy, x, w, rstd,
+                               dres, (bf16*)dres_lp, dw, T, d, accumulate);
+        else
+            hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, float>), grid, block, 0, stream, (const float*)dy, x, w, rstd,
+                               dres, (float*)dres_lp, dw, T, d, accumulate);
+    });
+    return mgen_check_launch("mgen_rmsnorm_bwd");
+}

@@ -1,0 +1,71 @@
+"""ctypes binding of libmgen_hip.so (the C-ABI declared in include/mgen.h).
+
+The library holds the hand-written gfx950 kernels. There is no fallback: if it is missing or a call fails the
+caller gets an exception.
+"""
+import ctypes
+import os
+from ctypes import c_void_p as P, c_int as I, c_long as L, c_float as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgen_hip.so")
+
+# name -> argument types (every function returns int, 0 = ok), in the order of include/mgen.h
+SIGNATURES = {
+    "mgen_gemm_bf16": [P, P, P, P, I, I, I, L, L, L, L, I, I, I, F, P],
+    "mgen_rmsnorm_fwd": [P, P, P, P, L, I, F, I, P],
+    "mgen_rmsnorm_bwd": [P, P, P, P, P, P, P, L, I, I, I, P],
+    "mgen_rope_table": [P, P, I, I, P],
+    "mgen_qknorm_rope_fwd": [P, L, P, P, L, L, P, P, P, P, I, L, I, I, I, F, I, P],
+    "mgen_qknorm_rope_bwd": [P, L, P, P, L, L, P, L, P, P, P, P, P, P, I, L, I, I, I, F, I, P],
+    "mgen_attn_fwd": [P, P, P, P, P, L, L, L, L, I, I, I, I, I, F, P],
+    "mgen_attn_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, P],
+    "mgen_swiglu_fwd": [P, P, L, I, I, P],
+    "mgen_swiglu_bwd": [P, P, P, L, I, P],
+    "mgen_embedding_fwd": [P, P, P, L, I, L, P, P],
+    "mgen_embedding_bwd": [P, P, P, L, I, L, P],
+    "mgen_cast": [P, P, L, I, P],
+    "mgen_ce_count": [P, L, I, L, P, P, P],
+    "mgen_ce_fwd_bwd": [P, P, L, L, I, L, I, L, P, F, P, P, I, I, P],
+    "mgen_ce_finalize": [P, L, P, P, P],
+    "mgen_grad_norm_clip": [P, L, F, P, P, P],
+    "mgen_adamw_step": [P, P, P, P, P, L, P, F, F, F, F, F, L, P],
+    "mgen_scale_f32": [P, L, F, P],
+    "mgen_axpy_f32": [P, P, L, F, P, P],
+    "mgen_scale_bf16": [P, L, F, P, P],
+}
+
+_lib = None
+
+
+class MgenError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MgenError(
+                f"{LIB_PATH} not found: build it with `make -C symbolic-music-generation_amd/csrc` "
+                "(the HIP kernel library is required; there is no CPU fallback)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        l.mgen_last_error.restype = ctypes.c_char_p
+        l.mgen_last_error.argtypes = []
+        l.mgen_version.restype = ctypes.c_int
+        l.mgen_sumsq_partial_count.restype = ctypes.c_int
+        l.mgen_device_info.argtypes = [I, ctypes.c_char_p, I]
+        l.mgen_device_info.restype = ctypes.c_int
+        _lib = l
+    return _lib
+
+
+def call(name, *args):
+    l = lib()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        raise MgenError(f"{name} failed ({rc}): {l.mgen_last_error().decode()}")

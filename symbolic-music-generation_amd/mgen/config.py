@@ -1,0 +1,46 @@
+"""Hyper-parameters of the decoder-only MIDI language model.
+
+Mirrors the Qwen3Config fields that the reference's default decoder actually reads
+(/root/reference/src/model/model.py:126-136 overrides hidden/layers/heads/kv-heads/intermediate/max-positions and the
+special token ids on top of the Qwen/Qwen3-0.6B base config; vocab_size 151936, head_dim 128, tied embeddings,
+rope_theta 1e6 and rms_norm_eps 1e-6 are inherited from that base config)."""
+from dataclasses import dataclass, asdict
+
+
+@dataclass
+class LMConfig:
+    vocab_size: int = 151936
+    hidden_size: int = 512
+    intermediate_size: int = 2048
+    num_hidden_layers: int = 14
+    num_attention_heads: int = 8
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    max_position_embeddings: int = 4096
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    tie_word_embeddings: bool = True
+    qk_norm: bool = True           # Qwen3 blocks normalise q and k per head; Llama blocks do not
+    bos_token_id: int = 1
+    eos_token_id: int = 2
+    pad_token_id: int = 0
+    lm_head_chunk_tokens: int = 8192   # rows of logits alive at once in the fused lm_head + cross-entropy
+
+    def to_dict(self):
+        return asdict(self)
+
+    @property
+    def qkv_width(self):
+        return (self.num_attention_heads + 2 * self.num_key_value_heads) * self.head_dim
+
+
+def default_decoder() -> LMConfig:
+    """The reference's default decoder (MidiQwen, src/model/model.py:120-139)."""
+    return LMConfig()
+
+
+def aria_style_llama() -> LMConfig:
+    """~650M Llama-architecture stand-in for the remote-code Aria model used by src/train_aria.py."""
+    return LMConfig(vocab_size=17727, hidden_size=1536, intermediate_size=6144, num_hidden_layers=16,
+                    num_attention_heads=24, num_key_value_heads=24, head_dim=64, max_position_embeddings=8192,
+                    rms_norm_eps=1e-6, rope_theta=10000.0, tie_word_embeddings=False, qk_norm=False)

@@ -1,0 +1,453 @@
+"""MidiLM: the decoder-only transformer over tokenized MIDI, running on hand-written gfx950 kernels.
+
+Call surface of the reference's wrapped model (/root/reference/src/model/model.py:142-143, which forwards to
+transformers' Qwen3ForCausalLM.forward): `model(input_ids, attention_mask=None, labels=None)` returns an object with
+`.loss` (0-dim fp32 tensor, differentiable) and `.logits`; `state_dict()` uses the HF parameter names
+(`model.layers.0.self_attn.q_proj.weight`, ...), `nn.Linear` weights are [out, in].
+
+Design for MI355X: all parameters live in ONE flat fp32 buffer (`flat_param`) with a flat fp32 gradient buffer and a
+flat bf16 shadow copy next to it; q/k/v and gate/up are adjacent in that buffer, so the fused QKV and gate-up GEMMs
+read them as single matrices. The optimizer, the gradient-norm reduction and the data-parallel all-reduce work on
+contiguous slices of these buffers. The whole network is one autograd node: forward saves the activations
+(288 GB of HBM: nothing is recomputed), the lm_head + cross-entropy forward and backward are fused per chunk of
+tokens so that the [T, V] logits are never alive at once, and backward walks the layers in reverse calling the
+dgrad/wgrad GEMMs and the fused norm/rope/attention backward kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import LMConfig
+
+_ALIGN = 64  # every tensor starts at a multiple of 64 elements in the flat buffers
+
+
+class CausalLMOutput:
+    """Minimal stand-in for transformers' CausalLMOutputWithPast: attribute and index access."""
+
+    def __init__(self, loss=None, logits=None):
+        self.loss = loss
+        self.logits = logits
+
+    def __getitem__(self, i):
+        return tuple(x for x in (self.loss, self.logits) if x is not None)[i]
+
+    def __iter__(self):
+        return iter(tuple(x for x in (self.loss, self.logits) if x is not None))
+
+
+def param_layout(cfg: LMConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                        cfg.intermediate_size)
+    out = [("model.embed_tokens.weight", (cfg.vocab_size, d))]
+    for l in range(cfg.num_hidden_layers):
+        p = f"model.layers.{l}."
+        out.append((p + "input_layernorm.weight", (d,)))
+        out.append((p + "self_attn.q_proj.weight", (H * Dh, d)))     # q, k, v adjacent = one [qkv_width, d] matrix
+        out.append((p + "self_attn.k_proj.weight", (KVH * Dh, d)))
+        out.append((p + "self_attn.v_proj.weight", (KVH * Dh, d)))
+        if cfg.qk_norm:
+            out.append((p + "self_attn.q_norm.weight", (Dh,)))
+            out.append((p + "self_attn.k_norm.weight", (Dh,)))
+        out.append((p + "self_attn.o_proj.weight", (d, H * Dh)))
+        out.append((p + "post_attention_layernorm.weight", (d,)))
+        out.append((p + "mlp.gate_proj.weight", (I, d)))             # gate, up adjacent = one [2I, d] matrix
+        out.append((p + "mlp.up_proj.weight", (I, d)))
+        out.append((p + "mlp.down_proj.weight", (d, I)))
+    out.append(("model.norm.weight", (d,)))
+    if not cfg.tie_word_embeddings:
+        out.append(("lm_head.weight", (cfg.vocab_size, d)))
+    return out
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def _register(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+class _LayerViews:
+    """Per-layer views into the flat buffers (fp32 master, fp32 grad, bf16 shadow)."""
+    pass
+
+
+class MidiLM(nn.Module):
+    def __init__(self, cfg: LMConfig, device="cuda", seed: Optional[int] = 0, compute_dtype=torch.bfloat16):
+        super().__init__()
+        if compute_dtype != torch.bfloat16:
+            raise NotImplementedError("only the bf16-mixed compute path (fp32 master weights) is built")
+        self.cfg = cfg
+        self.config = cfg
+        self.device_ = torch.device(device)
+        d = cfg.hidden_size
+        assert cfg.head_dim in (64, 128) and d % 8 == 0 and cfg.intermediate_size % 8 == 0
+        layout = param_layout(cfg)
+        offs, off = {}, 0
+        for name, shape in layout:
+            # q/k/v and gate/up must stay back to back: their sizes are multiples of _ALIGN already
+            n = _numel(shape)
+            offs[name] = off
+            off += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        self._offsets, self._shapes, self._total = offs, dict(layout), off
+        dev = self.device_
+        self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        self._shadow_version = -1
+        for name, shape in layout:
+            prm = nn.Parameter(self._view(self.flat_param, name), requires_grad=True)
+            prm.grad = self._view(self.flat_grad, name)
+            _register(self, name, prm)
+        if cfg.tie_word_embeddings:
+            _register(self, "lm_head.weight", self.model.embed_tokens.weight)
+        # layer views
+        self._layers = []
+        for l in range(cfg.num_hidden_layers):
+            self._layers.append(self._make_layer_views(l))
+        self._rope_cs = None
+        self._rope_npos = 0
+        self._lm_grad_tmp = None
+        self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
+        if seed is not None:
+            self.init_weights(seed)
+
+    # ------------------------------------------------------------------------------------------------
+    # parameter store
+    # ------------------------------------------------------------------------------------------------
+    def _view(self, flat, name, shape=None, count=None):
+        shape = shape or self._shapes[name]
+        n = count or _numel(shape)
+        o = self._offsets[name]
+        return flat[o:o + n].view(shape)
+
+    def _make_layer_views(self, l):
+        cfg = self.cfg
+        p = f"model.layers.{l}."
+        d, I = cfg.hidden_size, cfg.intermediate_size
+        v = _LayerViews()
+        for tag, flat in (("w", self.flat_param), ("g", self.flat_grad), ("s", self.flat_shadow)):
+            setattr(v, tag + "_ln1", self._view(flat, p + "input_layernorm.weight"))
+            setattr(v, tag + "_qkv", self._view(flat, p + "self_attn.q_proj.weight", (cfg.qkv_width, d)))
+            setattr(v, tag + "_o", self._view(flat, p + "self_attn.o_proj.weight"))
+            setattr(v, tag + "_ln2", self._view(flat, p + "post_attention_layernorm.weight"))
+            setattr(v, tag + "_gu", self._view(flat, p + "mlp.gate_proj.weight", (2 * I, d)))
+            setattr(v, tag + "_down", self._view(flat, p + "mlp.down_proj.weight"))
+            if cfg.qk_norm:
+                setattr(v, tag + "_qn", self._view(flat, p + "self_attn.q_norm.weight"))
+                setattr(v, tag + "_kn", self._view(flat, p + "self_attn.k_norm.weight"))
+            else:
+                setattr(v, tag + "_qn", None)
+                setattr(v, tag + "_kn", None)
+        return v
+
+    def init_weights(self, seed: int = 0):
+        """HF `_init_weights`: N(0, 0.02) for linear and embedding weights, ones for the norm gains."""
+        g = torch.Generator(device=self.flat_param.device).manual_seed(seed)
+        with torch.no_grad():
+            for name, prm in self.named_parameters():
+                if "norm" in name:
+                    prm.fill_(1.0)
+                else:
+                    prm.normal_(0.0, 0.02, generator=g)
+        self._shadow_version = -1
+
+    def _lm_head_name(self):
+        return "model.embed_tokens.weight" if self.cfg.tie_word_embeddings else "lm_head.weight"
+
+    def sync_shadow(self):
+        """Refresh the bf16 shadow from the fp32 master if the master changed through torch (the fused optimizer
+        writes both itself and calls mark_shadow_fresh)."""
+        if self._shadow_version != self.flat_param._version:
+            ops.cast(self.flat_param, self.flat_shadow)
+            self._shadow_version = self.flat_param._version
+
+    def mark_shadow_fresh(self):
+        self._shadow_version = self.flat_param._version
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_grad.zero_()
+        for name, prm in self.named_parameters():
+            if prm.grad is None:
+                prm.grad = self._view(self.flat_grad, name)
+
+    def _apply(self, fn, recurse=True):
+        # parameters are views of the flat buffers: moving them one by one would break the aliasing
+        probe = fn(torch.empty(0, device=self.flat_param.device))
+        if probe.device != self.flat_param.device or probe.dtype != torch.float32:
+            raise RuntimeError("MidiLM lives on the device it was created on in fp32 master precision; "
+                               "construct it with device=... instead of calling .to()/.half()")
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        own = dict(self.named_parameters())
+        own_names = set(own) | ({"lm_head.weight"} if self.cfg.tie_word_embeddings else set())
+        missing = [k for k in own if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in own_names]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing}, unexpected {unexpected}")
+        with torch.no_grad():
+            for k, prm in own.items():
+                if k in state_dict:
+                    src = state_dict[k]
+                    if tuple(src.shape) != tuple(prm.shape):
+                        raise RuntimeError(f"size mismatch for {k}: {tuple(src.shape)} vs {tuple(prm.shape)}")
+                    prm.copy_(src.to(device=prm.device, dtype=torch.float32))
+        self._shadow_version = -1
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    # ------------------------------------------------------------------------------------------------
+    # rope table
+    # ------------------------------------------------------------------------------------------------
+    def _rope_table(self, npos: int):
+        if self._rope_cs is None or self._rope_npos < npos:
+            cfg = self.cfg
+            npos = max(npos, cfg.max_position_embeddings)
+            # same expression as the reference (fp32 on the host), so inv_freq is bit-identical
+            inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, cfg.head_dim, 2, dtype=torch.float) / cfg.head_dim))
+            self._rope_cs = ops.rope_table(inv.to(self.flat_param.device), npos)
+            self._rope_npos = npos
+        return self._rope_cs
+
+    # ------------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, labels=None, num_logits_to_keep: int = 0, **unused):
+        """attention_mask is accepted for call compatibility. With right padding (what the reference's collators
+        produce) causal attention already keeps real tokens from seeing pads, so loss and gradients do not depend
+        on it; logits at pad positions are unspecified."""
+        if input_ids is None:
+            raise ValueError("You must specify input_ids")
+        if input_ids.dim() != 2:
+            raise ValueError("input_ids must be [batch, seq]")
+        if not input_ids.is_cuda:
+            raise RuntimeError("MidiLM runs on the GPU only: input_ids must be a CUDA/HIP tensor")
+        input_ids = input_ids.contiguous()
+        if labels is not None:
+            labels = labels.contiguous().to(torch.int64)
+        self.sync_shadow()
+        if labels is not None and torch.is_grad_enabled():
+            loss = _LMTrainFunction.apply(self, input_ids, labels, self.model.embed_tokens.weight)
+            return CausalLMOutput(loss=loss, logits=None)
+        with torch.no_grad():
+            hN, _ = self._run_layers(input_ids, save=None)
+            loss = None
+            if labels is not None:
+                loss, _ = self._lm_head_loss(hN, labels, with_grad=False)
+                return CausalLMOutput(loss=loss, logits=None)
+            B, S = input_ids.shape
+            if num_logits_to_keep:
+                hN = hN.view(B, S, -1)[:, -num_logits_to_keep:, :].reshape(-1, hN.shape[-1]).contiguous()
+            logits = self._logits(hN).view(B, -1, self.cfg.vocab_size)
+            return CausalLMOutput(loss=None, logits=logits)
+
+    def _logits(self, hN):
+        cfg = self.cfg
+        V = cfg.vocab_size
+        W = self._view(self.flat_shadow, self._lm_head_name())
+        T = hN.shape[0]
+        ld = (V + 7) // 8 * 8
+        buf = torch.empty(T, ld, dtype=torch.bfloat16, device=hN.device)
+        ops.gemm(hN, W, buf, T, V, cfg.hidden_size, hN.stride(0), W.stride(0), ld)
+        return buf[:, :V]
+
+    def _run_layers(self, input_ids, save: Optional[list], pos: Optional[torch.Tensor] = None):
+        cfg = self.cfg
+        B, S = input_ids.shape
+        T = B * S
+        d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                            cfg.intermediate_size)
+        dev = input_ids.device
+        bf = torch.bfloat16
+        NQ = cfg.qkv_width
+        QK = (H + KVH) * Dh
+        cs = self._rope_table(S)
+        scale = Dh ** -0.5
+        E = self.model.embed_tokens.weight
+        h = torch.empty(T, d, dtype=torch.float32, device=dev)
+        ops.embedding_fwd(input_ids, E, h, self._err_flag)
+        for l, v in enumerate(self._layers):
+            x1 = torch.empty(T, d, dtype=bf, device=dev)
+            rstd1 = torch.empty(T, dtype=torch.float32, device=dev)
+            ops.rmsnorm_fwd(h, v.w_ln1, x1, rstd1, cfg.rms_norm_eps)
+            qkv = torch.empty(T, NQ, dtype=bf, device=dev)
+            ops.linear_fwd(x1, v.s_qkv, qkv)
+            qk = torch.empty(T, QK, dtype=bf, device=dev)
+            ops.qknorm_rope_fwd(qkv, NQ, qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, S,
+                                T, H, KVH, Dh, cfg.rms_norm_eps)
+            att = torch.empty(T, H * Dh, dtype=bf, device=dev)
+            lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+            ops.attn_fwd(qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK, att.data_ptr(), lse,
+                         QK, QK, NQ, H * Dh, B, S, H, KVH, Dh, scale)
+            h_mid = torch.empty(T, d, dtype=torch.float32, device=dev)
+            ops.linear_fwd(att, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
+            x2 = torch.empty(T, d, dtype=bf, device=dev)
+            rstd2 = torch.empty(T, dtype=torch.float32, device=dev)
+            ops.rmsnorm_fwd(h_mid, v.w_ln2, x2, rstd2, cfg.rms_norm_eps)
+            gu = torch.empty(T, 2 * I, dtype=bf, device=dev)
+            ops.linear_fwd(x2, v.s_gu, gu)
+            act = torch.empty(T, I, dtype=bf, device=dev)
+            ops.swiglu_fwd(gu, act)
+            h_out = torch.empty(T, d, dtype=torch.float32, device=dev)
+            ops.linear_fwd(act, v.s_down, h_out, ops.OUT_F32_RESID_BF16ROUND, h_mid)
+            if save is not None:
+                save.append((h, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act))
+            h = h_out
+        xN = torch.empty(T, d, dtype=bf, device=dev)
+        rstdN = torch.empty(T, dtype=torch.float32, device=dev)
+        ops.rmsnorm_fwd(h, self.model.norm.weight, xN, rstdN, cfg.rms_norm_eps)
+        return xN, (h, rstdN)
+
+    def _lm_head_loss(self, xN, labels, with_grad: bool):
+        """Fused lm_head + shifted cross entropy over chunks of tokens. With with_grad, also returns
+        d(loss)/d(xN) (bf16) and leaves d(loss)/d(W_lm_head) in self._lm_grad_tmp (fp32), both for upstream grad 1."""
+        cfg = self.cfg
+        B, S = labels.shape
+        T = B * S
+        V, d = cfg.vocab_size, cfg.hidden_size
+        dev = xN.device
+        W = self._view(self.flat_shadow, self._lm_head_name())
+        ld = (V + 7) // 8 * 8
+        chunk = min(cfg.lm_head_chunk_tokens, T)
+        inv_count = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.ce_count(labels, inv_count)
+        row_loss = torch.empty(T, dtype=torch.float32, device=dev)
+        logits = torch.empty(chunk, ld, dtype=torch.bfloat16, device=dev)
+        dxN = torch.empty(T, d, dtype=torch.bfloat16, device=dev) if with_grad else None
+        if with_grad:
+            if self._lm_grad_tmp is None:
+                self._lm_grad_tmp = torch.empty(V, d, dtype=torch.float32, device=dev)
+        first = True
+        for t0 in range(0, T, chunk):
+            n = min(chunk, T - t0)
+            xc = xN[t0:t0 + n]
+            ops.gemm(xc, W, logits, n, V, d, xc.stride(0), W.stride(0), ld)
+            ops.ce_fwd_bwd(logits, labels, t0, n, V, ld, S, inv_count, 1.0, row_loss, None, write_grad=with_grad)
+            if with_grad:
+                # dxN[c] = dlogits[c] @ W ; dW += dlogits[c]^T @ xN[c]
+                ops.gemm(logits, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
+                ops.gemm(logits, xc, self._lm_grad_tmp, V, d, n, ld, xc.stride(0), d, True, True,
+                         ops.OUT_F32 if first else ops.OUT_F32_ACC)
+                first = False
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ops.ce_finalize(row_loss, inv_count, loss)
+        return loss, dxN
+
+    # ------------------------------------------------------------------------------------------------
+    # backward through the layer stack; gradients are ACCUMULATED into flat_grad
+    # ------------------------------------------------------------------------------------------------
+    def _backward_layers(self, input_ids, saved, final, dxN, grad_hook=None):
+        cfg = self.cfg
+        B, S = input_ids.shape
+        T = B * S
+        d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                            cfg.intermediate_size)
+        dev = input_ids.device
+        bf = torch.bfloat16
+        NQ = cfg.qkv_width
+        QK = (H + KVH) * Dh
+        cs = self._rope_table(S)
+        scale = Dh ** -0.5
+        h_last, rstdN = final
+        dh = torch.empty(T, d, dtype=torch.float32, device=dev)
+        dh_lp = torch.empty(T, d, dtype=bf, device=dev)
+        g_norm = self._view(self.flat_grad, "model.norm.weight")
+        ops.rmsnorm_bwd(dxN, h_last, self.model.norm.weight, rstdN, dh, dh_lp, g_norm, accumulate=False)
+        if grad_hook is not None:
+            grad_hook("head")
+        dact = torch.empty(T, I, dtype=bf, device=dev)
+        dgu = torch.empty(T, 2 * I, dtype=bf, device=dev)
+        dx = torch.empty(T, d, dtype=bf, device=dev)
+        datt = torch.empty(T, H * Dh, dtype=bf, device=dev)
+        dqkv = torch.empty(T, NQ, dtype=bf, device=dev)
+        delta = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+        for l in range(cfg.num_hidden_layers - 1, -1, -1):
+            v = self._layers[l]
+            h_in, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act = saved[l]
+            # ---- MLP branch
+            ops.linear_dgrad(dh_lp, v.s_down, dact)
+            ops.linear_wgrad(dh_lp, act, v.g_down)
+            ops.swiglu_bwd(gu, dact, dgu)
+            ops.linear_dgrad(dgu, v.s_gu, dx)
+            ops.linear_wgrad(dgu, x2, v.g_gu)
+            ops.rmsnorm_bwd(dx, h_mid, v.w_ln2, rstd2, dh, dh_lp, v.g_ln2, accumulate=True)
+            # ---- attention branch
+            ops.linear_dgrad(dh_lp, v.s_o, datt)
+            ops.linear_wgrad(dh_lp, att, v.g_o)
+            qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK
+            dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + 2 * H * Dh, dqkv.data_ptr() + 2 * QK
+            ops.attn_bwd(qp, kp, vp, att.data_ptr(), datt.data_ptr(), lse, delta, dqp, dkp, dvp,
+                         QK, QK, NQ, H * Dh, H * Dh, NQ, NQ, NQ, B, S, H, KVH, Dh, scale)
+            ops.qknorm_rope_bwd(dqp, NQ, dqp, dkp, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn, cs, None, S, T, H,
+                                KVH, Dh, cfg.rms_norm_eps)
+            ops.linear_dgrad(dqkv, v.s_qkv, dx)
+            ops.linear_wgrad(dqkv, x1, v.g_qkv)
+            ops.rmsnorm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, accumulate=True)
+            saved[l] = None
+            if grad_hook is not None:
+                grad_hook(l)
+        ops.embedding_bwd(input_ids, dh, self._view(self.flat_grad, "model.embed_tokens.weight"))
+        if grad_hook is not None:
+            grad_hook("embed")
+
+    # layout helpers for the data-parallel reducer -------------------------------------------------------
+    def grad_ranges(self):
+        """Contiguous [start, end) slices of flat_grad in the order backward finishes them: head (final norm and an
+        untied lm_head), layers L-1..0, embedding."""
+        cfg = self.cfg
+        o = self._offsets
+        total = self._total
+        out = [("head", o["model.norm.weight"], total)]
+        for l in range(cfg.num_hidden_layers - 1, -1, -1):
+            start = o[f"model.layers.{l}.input_layernorm.weight"]
+            end = o[f"model.layers.{l + 1}.input_layernorm.weight"] if l + 1 < cfg.num_hidden_layers else \
+                o["model.norm.weight"]
+            out.append((l, start, end))
+        out.append(("embed", 0, o["model.layers.0.input_layernorm.weight"] if cfg.num_hidden_layers else
+                    o["model.norm.weight"]))
+        return out
+
+
+class _LMTrainFunction(torch.autograd.Function):
+    """The whole network as one autograd node (see module docstring)."""
+
+    @staticmethod
+    def forward(ctx, model: MidiLM, input_ids, labels, _anchor):
+        saved: list = []
+        xN, final = model._run_layers(input_ids, save=saved)
+        loss, dxN = model._lm_head_loss(xN, labels, with_grad=True)
+        ctx.model, ctx.input_ids, ctx.saved, ctx.final, ctx.dxN = model, input_ids, saved, final, dxN
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model: MidiLM = ctx.model
+        if ctx.saved is None:
+            raise RuntimeError("MidiLM backward called twice on the same forward")
+        # the upstream gradient stays on the device: everything below is linear in it
+        go = grad_out.to(torch.float32).contiguous()
+        dxN = ctx.dxN
+        ops.scale_bf16_(dxN, 1.0, go)
+        name = model._lm_head_name()
+        ops.axpy_(model._view(model.flat_grad, name).view(-1), model._lm_grad_tmp.view(-1), 1.0, go)
+        model._backward_layers(ctx.input_ids, ctx.saved, ctx.final, dxN, getattr(model, "_grad_hook", None))
+        ctx.saved = None
+        for pname, prm in model.named_parameters():
+            if prm.grad is None:
+                prm.grad = model._view(model.flat_grad, pname)
+        return None, None, None, None

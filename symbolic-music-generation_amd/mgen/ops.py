@@ -1,0 +1,157 @@
+"""Tensor-level wrappers over the C-ABI kernels: take torch CUDA(HIP) tensors, pass raw device pointers, sizes,
+strides and the current HIP stream. torch is used for device memory and streams only; every computation below runs
+in libmgen_hip.so."""
+import torch
+
+from ._lib import call
+
+# GEMM epilogues (must match csrc/gemm.hip)
+OUT_BF16, OUT_F32, OUT_F32_ACC, OUT_F32_RESID_BF16ROUND, OUT_F32_RESID = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mgen ops need tensors on the GPU (no CPU fallback exists)")
+
+
+def gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode=OUT_BF16, resid=None, ldr=0,
+         alpha=1.0):
+    """c[M,N] (+)= op(a)[M,K] @ op(b)[K,N]; a is [M,K] (or [K,M] if trans_a), b is [N,K] (or [K,N] if trans_b)."""
+    _need_gpu(a, b, c)
+    call("mgen_gemm_bf16", _p(a), _p(b), _p(c), _p(resid), M, N, K, lda, ldb, ldc, ldr, int(trans_a), int(trans_b),
+         out_mode, alpha, _stream())
+
+
+def linear_fwd(x, w, out, out_mode=OUT_BF16, resid=None):
+    """out[T,N] = x[T,K] @ w[N,K]^T for contiguous 2-D tensors."""
+    T, K = x.shape
+    N = w.shape[0]
+    gemm(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), False, False, out_mode, resid,
+         resid.stride(0) if resid is not None else 0)
+
+
+def linear_dgrad(dy, w, dx):
+    """dx[T,K] = dy[T,N] @ w[N,K]."""
+    T, N = dy.shape
+    K = w.shape[1]
+    gemm(dy, w, dx, T, K, N, dy.stride(0), w.stride(0), dx.stride(0), False, True, OUT_BF16)
+
+
+def linear_wgrad(dy, x, dw, accumulate=True, n_rows=None, n_cols=None):
+    """dw[N,K] (+)= dy[T,N]^T @ x[T,K] (fp32 output)."""
+    T = dy.shape[0]
+    N = n_rows if n_rows is not None else dy.shape[1]
+    K = n_cols if n_cols is not None else x.shape[1]
+    gemm(dy, x, dw, N, K, T, dy.stride(0), x.stride(0), dw.stride(0), True, True,
+         OUT_F32_ACC if accumulate else OUT_F32)
+
+
+def rmsnorm_fwd(x, w, y, rstd, eps):
+    T, d = x.shape
+    call("mgen_rmsnorm_fwd", _p(x), _p(w), _p(y), _p(rstd), T, d, eps, int(y.dtype == torch.bfloat16), _stream())
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres, dres_lp, dw, accumulate):
+    T, d = x.shape
+    call("mgen_rmsnorm_bwd", _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dres_lp), _p(dw), T, d, int(accumulate),
+         int(dy.dtype == torch.bfloat16), _stream())
+
+
+def rope_table(inv_freq, npos):
+    half = inv_freq.numel()
+    cs = torch.empty(npos, half, 2, dtype=torch.float32, device=inv_freq.device)
+    call("mgen_rope_table", _p(inv_freq), _p(cs), npos, half, _stream())
+    return cs
+
+
+def qknorm_rope_fwd(qkv, ld_in, qout, kout, ld_q, ld_k, wq, wk, cs, pos, S, T, HQ, HK, D, eps):
+    call("mgen_qknorm_rope_fwd", _p(qkv), ld_in, qout, kout, ld_q, ld_k, _p(wq), _p(wk), _p(cs), _p(pos), S, T, HQ,
+         HK, D, eps, int(qkv.dtype == torch.bfloat16), _stream())
+
+
+def qknorm_rope_bwd(dqk, ld_in, dq_raw, dk_raw, ld_q, ld_k, raw, ld_raw, wq, wk, dwq, dwk, cs, pos, S, T, HQ, HK, D,
+                    eps, is_bf16=True):
+    call("mgen_qknorm_rope_bwd", dqk, ld_in, dq_raw, dk_raw, ld_q, ld_k, _p(raw), ld_raw, _p(wq), _p(wk), _p(dwq),
+         _p(dwk), _p(cs), _p(pos), S, T, HQ, HK, D, eps, int(is_bf16), _stream())
+
+
+def attn_fwd(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, D, scale):
+    """q/k/v/out are raw device pointers (ints) of token-major views; strides in elements."""
+    call("mgen_attn_fwd", q, k, v, out, _p(lse), sq, sk, sv, so, B, S, H, KVH, D, scale, _stream())
+
+
+def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, sq, sk, sv, so, sdo, sdq, sdk, sdv, B, S, H, KVH, D, scale):
+    call("mgen_attn_bwd", q, k, v, out, dout, _p(lse), _p(delta), dq, dk, dv, sq, sk, sv, so, sdo, sdq, sdk, sdv, B,
+         S, H, KVH, D, scale, _stream())
+
+
+def swiglu_fwd(gu, act, round_silu=True):
+    T, I = act.shape
+    call("mgen_swiglu_fwd", _p(gu), _p(act), T, I, int(round_silu), _stream())
+
+
+def swiglu_bwd(gu, dact, dgu):
+    T, I = dact.shape
+    call("mgen_swiglu_bwd", _p(gu), _p(dact), _p(dgu), T, I, _stream())
+
+
+def embedding_fwd(ids, table, out, err_flag=None):
+    T = ids.numel()
+    V, d = table.shape
+    call("mgen_embedding_fwd", _p(ids), _p(table), _p(out), T, d, V, _p(err_flag), _stream())
+
+
+def embedding_bwd(ids, dout, dtable):
+    T = ids.numel()
+    V, d = dtable.shape
+    call("mgen_embedding_bwd", _p(ids), _p(dout), _p(dtable), T, d, V, _stream())
+
+
+def cast(src, dst):
+    kind = 0 if src.dtype == torch.float32 else 1
+    call("mgen_cast", _p(src), _p(dst), src.numel(), kind, _stream())
+
+
+def ce_count(labels, inv_count, count=None, ignore_index=-100):
+    B, S = labels.shape
+    call("mgen_ce_count", _p(labels), B, S, ignore_index, _p(inv_count), _p(count), _stream())
+
+
+def ce_fwd_bwd(logits, labels, tok0, rows, V, ld, S, inv_count, grad_scale, row_loss, lse_out=None, write_grad=True,
+               ignore_index=-100):
+    call("mgen_ce_fwd_bwd", _p(logits), _p(labels), tok0, rows, V, ld, S, ignore_index, _p(inv_count), grad_scale,
+         _p(row_loss), _p(lse_out), int(write_grad), int(logits.dtype == torch.bfloat16), _stream())
+
+
+def ce_finalize(row_loss, inv_count, loss):
+    call("mgen_ce_finalize", _p(row_loss), row_loss.numel(), _p(inv_count), _p(loss), _stream())
+
+
+def grad_norm_clip(grad, max_norm, workspace, out):
+    call("mgen_grad_norm_clip", _p(grad), grad.numel(), max_norm, _p(workspace), _p(out), _stream())
+
+
+def adamw_step(p, g, m, v, shadow, clip, lr, beta1, beta2, eps, wd, step):
+    call("mgen_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(clip), lr, beta1, beta2, eps, wd,
+         step, _stream())
+
+
+def scale_(x, s):
+    call("mgen_scale_f32", _p(x), x.numel(), s, _stream())
+
+
+def axpy_(y, x, a=1.0, a_dev=None):
+    call("mgen_axpy_f32", _p(y), _p(x), x.numel(), a, _p(a_dev), _stream())
+
+
+def scale_bf16_(x, a=1.0, a_dev=None):
+    call("mgen_scale_bf16", _p(x), x.numel(), a, _p(a_dev), _stream())

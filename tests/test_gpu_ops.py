@@ -1,0 +1,385 @@
+"""Per-kernel parity tests: every C-ABI kernel against plain torch fp32 arithmetic on the CPU for the same
+(bf16-rounded) inputs. Run on the GPU box with -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mgen import ops as o
+    return o
+
+
+# ----------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 200, 136), (1000, 72, 1096)])
+def test_gemm_layouts(ops, ta, tb, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = bf(torch.randn(M, K, generator=g))
+    B = bf(torch.randn(K, N, generator=g))
+    ref = A.float() @ B.float()
+    ld = lambda n: (n + 7) // 8 * 8
+    # stored forms, zero padded to a multiple of 8 columns
+    def stored(mat):
+        r, c = mat.shape
+        out = torch.zeros(r, ld(c), dtype=torch.bfloat16)
+        out[:, :c] = mat
+        return out.to(dev())
+    a_st = stored(A.t().contiguous()) if ta else stored(A)
+    b_st = stored(B) if tb else stored(B.t().contiguous())
+    ldc = ld(N) + 8
+    c = torch.full((M, ldc), 7.0, dtype=torch.float32, device=dev())
+    ops.gemm(a_st, b_st, c, M, N, K, a_st.stride(0), b_st.stride(0), ldc, ta, tb, ops.OUT_F32)
+    assert rel(c[:, :N], ref) < 2e-5
+    assert bool((c[:, N:] == 7.0).all()), "wrote outside the N columns"
+    cb = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a_st, b_st, cb, M, N, K, a_st.stride(0), b_st.stride(0), ldc, ta, tb, ops.OUT_BF16)
+    assert rel(cb[:, :N].float(), ref) < 1e-2
+    assert bool((cb[:, N:] == 0).all())
+    # accumulate and residual epilogues
+    ops.gemm(a_st, b_st, c, M, N, K, a_st.stride(0), b_st.stride(0), ldc, ta, tb, ops.OUT_F32_ACC)
+    assert rel(c[:, :N], 2 * ref) < 2e-5
+    res = torch.randn(M, N, generator=g).to(dev())
+    out = torch.empty(M, N, dtype=torch.float32, device=dev())
+    ops.gemm(a_st, b_st, out, M, N, K, a_st.stride(0), b_st.stride(0), N, ta, tb, ops.OUT_F32_RESID_BF16ROUND, res, N)
+    assert rel(out, res.cpu() + bf(ref).float()) < 1e-2
+
+
+def test_gemm_exact_identity_asymmetric(ops):
+    """A = I against an asymmetric integer B: catches swapped rows/columns and a wrong k order exactly."""
+    n = 128
+    A = torch.eye(n)
+    B = (torch.arange(n)[:, None] * 3 + torch.arange(n)[None, :] * 1).float() % 251  # B[k][j], asymmetric
+    for ta in (False, True):
+        for tb in (False, True):
+            a_st = bf(A).to(dev())
+            b_st = bf(B if tb else B.t().contiguous()).to(dev())
+            c = torch.empty(n, n, dtype=torch.float32, device=dev())
+            ops.gemm(a_st, b_st, c, n, n, n, n, n, n, ta, tb, ops.OUT_F32)
+            assert torch.equal(c.cpu(), B), (ta, tb)
+    # and a non-trivial permutation on the A side (row i of A picks row (5i+3) mod n of B)
+    perm = (torch.arange(n) * 5 + 3) % n
+    A = torch.zeros(n, n)
+    A[torch.arange(n), perm] = 1.0
+    for ta in (False, True):
+        a_st = bf(A.t().contiguous() if ta else A).to(dev())
+        b_st = bf(B).to(dev())
+        c = torch.empty(n, n, dtype=torch.float32, device=dev())
+        ops.gemm(a_st, b_st, c, n, n, n, n, n, n, ta, True, ops.OUT_F32)
+        assert torch.equal(c.cpu(), B[perm]), ta
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from mgen._lib import MgenError
+    a = torch.zeros(8, 8, dtype=torch.bfloat16, device=dev())
+    c = torch.zeros(8, 8, dtype=torch.float32, device=dev())
+    with pytest.raises(MgenError):
+        ops.gemm(a, a, c, 8, 8, 8, 4, 8, 8)  # lda not a multiple of 8
+    with pytest.raises(MgenError):
+        ops.gemm(a, a, c, 8, 8, 8, 8, 8, 8, out_mode=99)
+
+
+# ----------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("T,d", [(7, 512), (1000, 256), (33, 1536)])
+def test_rmsnorm_fwd_bwd(ops, T, d):
+    g = torch.Generator().manual_seed(T + d)
+    x = torch.randn(T, d, generator=g) * 2
+    w = 1 + 0.1 * torch.randn(d, generator=g)
+    dy = bf(torch.randn(T, d, generator=g))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y = R.rmsnorm(xr, wr, 1e-6)
+    y.backward(dy.float())
+    xd, wd = x.to(dev()), w.to(dev())
+    yb = torch.empty(T, d, dtype=torch.bfloat16, device=dev())
+    yf = torch.empty(T, d, dtype=torch.float32, device=dev())
+    rstd = torch.empty(T, dtype=torch.float32, device=dev())
+    ops.rmsnorm_fwd(xd, wd, yf, rstd, 1e-6)
+    assert rel(yf, y.detach()) < 1e-5
+    ops.rmsnorm_fwd(xd, wd, yb, rstd, 1e-6)
+    assert torch.equal(yb.cpu(), bf(yf.cpu())) or rel(yb.float(), y.detach()) < 1e-2
+    prev = torch.randn(T, d, generator=g)
+    dres = prev.clone().to(dev())
+    dlp = torch.empty(T, d, dtype=torch.bfloat16, device=dev())
+    dw = torch.zeros(d, dtype=torch.float32, device=dev())
+    ops.rmsnorm_bwd(dy.to(dev()), xd, wd, rstd, dres, dlp, dw, accumulate=True)
+    assert rel(dres, prev + xr.grad) < 1e-5
+    assert rel(dw, wr.grad) < 1e-4
+    assert rel(dlp.float(), prev + xr.grad) < 1e-2
+    ops.rmsnorm_bwd(dy.to(dev()), xd, wd, rstd, dres, None, dw, accumulate=False)
+    assert rel(dres, xr.grad) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------- rope
+@pytest.mark.parametrize("D,norm", [(128, True), (64, False), (128, False), (64, True)])
+def test_qknorm_rope_fwd_bwd(ops, D, norm):
+    B, S, HQ, HK = 2, 37, 3, 2
+    T = B * S
+    g = torch.Generator().manual_seed(D + norm)
+    NQ = (HQ + 2 * HK) * D
+    qkv = bf(torch.randn(T, NQ, generator=g))
+    wq = 1 + 0.2 * torch.randn(D, generator=g)
+    wk = 1 + 0.2 * torch.randn(D, generator=g)
+    theta = 1e6
+    pos = torch.arange(S)[None].expand(B, S)
+    cos, sin = R.rope_cos_sin(pos, D, theta)
+
+    def ref(qkv_f, wq_, wk_):
+        q = qkv_f[:, :HQ * D].view(B, S, HQ, D)
+        k = qkv_f[:, HQ * D:(HQ + HK) * D].view(B, S, HK, D)
+        if norm:
+            q = R.rmsnorm(bf(q), wq_, 1e-6)
+            k = R.rmsnorm(bf(k), wk_, 1e-6)
+        q = R.apply_rope(q.transpose(1, 2).float(), cos, sin).transpose(1, 2)
+        k = R.apply_rope(k.transpose(1, 2).float(), cos, sin).transpose(1, 2)
+        return q.reshape(T, HQ * D), k.reshape(T, HK * D)
+
+    q_ref, k_ref = ref(qkv.float(), wq, wk)
+    inv = R.rope_inv_freq(D, theta).to(dev())
+    cs = ops.rope_table(inv, 64)
+    assert rel(cs[:S, :, 0], cos[0, :, :D // 2]) < 1e-6 and rel(cs[:S, :, 1], sin[0, :, :D // 2]) < 1e-6
+    QK = (HQ + HK) * D
+    out = torch.empty(T, QK, dtype=torch.bfloat16, device=dev())
+    qd = qkv.to(dev())
+    wqd, wkd = (wq.to(dev()), wk.to(dev())) if norm else (None, None)
+    ops.qknorm_rope_fwd(qd, NQ, out.data_ptr(), out.data_ptr() + 2 * HQ * D, QK, QK, wqd, wkd, cs, None, S, T, HQ,
+                        HK, D, 1e-6)
+    assert rel(out[:, :HQ * D].float(), q_ref) < 1e-2
+    assert rel(out[:, HQ * D:].float(), k_ref) < 1e-2
+    # explicit positions give the same result
+    posd = pos.reshape(-1).to(torch.int32).to(dev())
+    out2 = torch.empty_like(out)
+    ops.qknorm_rope_fwd(qd, NQ, out2.data_ptr(), out2.data_ptr() + 2 * HQ * D, QK, QK, wqd, wkd, cs, posd, S, T, HQ,
+                        HK, D, 1e-6)
+    assert torch.equal(out, out2)
+
+    # backward against autograd of the fp32 formula (rounding of the normalised value treated as identity)
+    xf = qkv.float().clone().requires_grad_(True)
+    wq_r = wq.clone().requires_grad_(True)
+    wk_r = wk.clone().requires_grad_(True)
+    q = xf[:, :HQ * D].view(B, S, HQ, D)
+    k = xf[:, HQ * D:(HQ + HK) * D].view(B, S, HK, D)
+    if norm:
+        q = R.rmsnorm(q, wq_r, 1e-6)
+        k = R.rmsnorm(k, wk_r, 1e-6)
+    q = R.apply_rope(q.transpose(1, 2), cos, sin).transpose(1, 2).reshape(T, HQ * D)
+    k = R.apply_rope(k.transpose(1, 2), cos, sin).transpose(1, 2).reshape(T, HK * D)
+    dqk = bf(torch.randn(T, NQ, generator=g))
+    (q * dqk[:, :HQ * D].float()).sum().backward(retain_graph=True)
+    (k * dqk[:, HQ * D:QK].float()).sum().backward()
+    buf = dqk.clone().to(dev())
+    dwq = torch.zeros(D, dtype=torch.float32, device=dev())
+    dwk = torch.zeros(D, dtype=torch.float32, device=dev())
+    p = buf.data_ptr()
+    ops.qknorm_rope_bwd(p, NQ, p, p + 2 * HQ * D, NQ, NQ, qd, NQ, wqd, wkd, dwq if norm else None,
+                        dwk if norm else None, cs, None, S, T, HQ, HK, D, 1e-6)
+    assert rel(buf[:, :QK].float(), xf.grad[:, :QK]) < 1.5e-2
+    assert torch.equal(buf[:, QK:].cpu(), dqk[:, QK:]), "v section must be untouched"
+    if norm:
+        assert rel(dwq, wq_r.grad) < 1e-3 and rel(dwk, wk_r.grad) < 1e-3
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale):
+    # q,k,v [B,S,H,D] fp32 leaf tensors
+    o = R.causal_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale)
+    return o  # [B,S,H*D]
+
+
+@pytest.mark.parametrize("B,S,H,KVH", [(1, 128, 1, 1), (2, 200, 2, 2), (1, 384, 4, 2), (2, 64, 2, 1), (1, 777, 1, 1)])
+def test_attention_fwd_bwd(ops, B, S, H, KVH):
+    D = 128
+    g = torch.Generator().manual_seed(B * 1000 + S + H)
+    T = B * S
+    q = bf(torch.randn(B, S, H, D, generator=g))
+    k = bf(torch.randn(B, S, KVH, D, generator=g))
+    v = bf(torch.randn(B, S, KVH, D, generator=g))
+    do = bf(torch.randn(B, S, H * D, generator=g))
+    scale = D ** -0.5
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    o_ref = _attn_ref(qr, kr, vr, scale)
+    o_ref.backward(do.float())
+    # fused layout as the model uses it: q|k in one buffer, v inside the projection output
+    QK = (H + KVH) * D
+    NQ = (H + 2 * KVH) * D
+    qk = torch.cat([q.reshape(T, H * D), k.reshape(T, KVH * D)], dim=1).contiguous().to(dev())
+    qkv = torch.zeros(T, NQ, dtype=torch.bfloat16)
+    qkv[:, QK:] = v.reshape(T, KVH * D)
+    qkv = qkv.to(dev())
+    out = torch.zeros(T, H * D, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device=dev())
+    qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * D, qkv.data_ptr() + 2 * QK
+    ops.attn_fwd(qp, kp, vp, out.data_ptr(), lse, QK, QK, NQ, H * D, B, S, H, KVH, D, scale)
+    assert rel(out.float().view(B, S, H * D), o_ref.detach()) < 1e-2
+    # LSE check
+    rep = H // KVH
+    kk = k.float().repeat_interleave(rep, dim=2)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q.float(), kk) * scale
+    sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    assert rel(lse, torch.logsumexp(sc, dim=-1)) < 1e-4
+
+    dqkv = torch.zeros(T, NQ, dtype=torch.bfloat16, device=dev())
+    delta = torch.empty(B, H, S, dtype=torch.float32, device=dev())
+    dod = do.reshape(T, H * D).to(dev())
+    dp = dqkv.data_ptr()
+    ops.attn_bwd(qp, kp, vp, out.data_ptr(), dod.data_ptr(), lse, delta, dp, dp + 2 * H * D, dp + 2 * QK,
+                 QK, QK, NQ, H * D, H * D, NQ, NQ, NQ, B, S, H, KVH, D, scale)
+    assert rel(dqkv[:, :H * D].float(), qr.grad.reshape(T, H * D)) < 2e-2
+    assert rel(dqkv[:, H * D:QK].float(), kr.grad.reshape(T, KVH * D)) < 2e-2
+    assert rel(dqkv[:, QK:].float(), vr.grad.reshape(T, KVH * D)) < 2e-2
+
+
+def test_attention_online_softmax_rescale(ops):
+    """One key row spiked against one query row so that the running max jumps at a late tile."""
+    B, S, H, D = 1, 256, 1, 128
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, S, H, D, generator=g) * 0.5
+    k = torch.randn(B, S, H, D, generator=g) * 0.5
+    v = torch.randn(B, S, H, D, generator=g)
+    k[0, 190] = q[0, 250] * 6.0     # huge score for query 250 (and large for others) at key 190 (third tile)
+    k[0, 3] = q[0, 100] * 5.0
+    q, k, v = bf(q), bf(k), bf(v)
+    scale = D ** -0.5
+    o_ref = _attn_ref(q.float(), k.float(), v.float(), scale)
+    T = B * S
+    qd, kd, vd = (t.reshape(T, D).contiguous().to(dev()) for t in (q, k, v))
+    out = torch.zeros(T, D, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device=dev())
+    ops.attn_fwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), lse, D, D, D, D, B, S, H, H, D, scale)
+    assert rel(out.float().view(B, S, D), o_ref) < 1e-2
+
+
+# ----------------------------------------------------------------------------------------------- elementwise
+def test_swiglu(ops):
+    T, I = 37, 256
+    g = torch.Generator().manual_seed(3)
+    gu = bf(torch.randn(T, 2 * I, generator=g) * 2)
+    da = bf(torch.randn(T, I, generator=g))
+    gr = gu.float().clone().requires_grad_(True)
+    act_ref = torch.nn.functional.silu(gr[:, :I]) * gr[:, I:]
+    act_ref.backward(da.float())
+    act = torch.empty(T, I, dtype=torch.bfloat16, device=dev())
+    ops.swiglu_fwd(gu.to(dev()), act)
+    emul = bf(bf(torch.nn.functional.silu(gu[:, :I].float())).float() * gu[:, I:].float())
+    assert rel(act.float(), emul.float()) < 8e-3
+    dgu = torch.empty(T, 2 * I, dtype=torch.bfloat16, device=dev())
+    ops.swiglu_bwd(gu.to(dev()), da.to(dev()), dgu)
+    assert rel(dgu.float(), gr.grad) < 1e-2
+
+
+def test_embedding(ops):
+    V, d, T = 1000, 512, 300
+    g = torch.Generator().manual_seed(4)
+    table = torch.randn(V, d, generator=g)
+    ids = torch.randint(0, V, (T,), generator=g)
+    ids[:50] = 7  # heavy collisions
+    out = torch.empty(T, d, dtype=torch.float32, device=dev())
+    err = torch.zeros(1, dtype=torch.int32, device=dev())
+    ops.embedding_fwd(ids.to(dev()), table.to(dev()), out, err)
+    assert torch.equal(out.cpu(), table[ids]) and int(err) == 0
+    dout = torch.randn(T, d, generator=g)
+    dt = torch.zeros(V, d, dtype=torch.float32, device=dev())
+    ops.embedding_bwd(ids.to(dev()), dout.to(dev()), dt)
+    ref = torch.zeros(V, d).index_add_(0, ids, dout)
+    assert rel(dt, ref) < 1e-5
+    bad = ids.clone()
+    bad[3] = V + 5
+    ops.embedding_fwd(bad.to(dev()), table.to(dev()), out, err)
+    assert int(err) == 1
+
+
+@pytest.mark.parametrize("V", [1024, 1031, 30000])
+def test_cross_entropy(ops, V):
+    B, S = 3, 17
+    T = B * S
+    g = torch.Generator().manual_seed(V)
+    ld = (V + 7) // 8 * 8
+    logits = bf(torch.randn(T, V, generator=g) * 3)
+    labels = torch.randint(0, V, (B, S), generator=g)
+    labels[0, 3:6] = -100
+    labels[2, :] = -100
+    lr = logits.float().clone().requires_grad_(True)
+    loss_ref = R.causal_lm_loss(lr.view(B, S, V), labels)
+    loss_ref.backward()
+    buf = torch.full((T, ld), 5.0, dtype=torch.bfloat16)
+    buf[:, :V] = logits
+    buf = buf.to(dev())
+    lab = labels.to(dev())
+    inv = torch.empty(1, dtype=torch.float32, device=dev())
+    cnt = torch.empty(1, dtype=torch.int32, device=dev())
+    ops.ce_count(lab, inv, cnt)
+    n_valid = int((torch.nn.functional.pad(labels, (0, 1), value=-100)[:, 1:] != -100).sum())
+    assert int(cnt) == n_valid
+    row_loss = torch.empty(T, dtype=torch.float32, device=dev())
+    ops.ce_fwd_bwd(buf, lab, 0, T, V, ld, S, inv, 1.0, row_loss)
+    loss = torch.empty((), dtype=torch.float32, device=dev())
+    ops.ce_finalize(row_loss, inv, loss)
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * abs(float(loss_ref))
+    assert rel(buf[:, :V].float(), lr.grad) < 1e-2
+    assert bool((buf[:, V:] == 0).all())
+    # chunked call (tok0 offset) gives the same rows
+    buf2 = torch.full((T, ld), 5.0, dtype=torch.bfloat16)
+    buf2[:, :V] = logits
+    buf2 = buf2.to(dev())
+    h = 20
+    ops.ce_fwd_bwd(buf2[:h], lab, 0, h, V, ld, S, inv, 1.0, row_loss)
+    ops.ce_fwd_bwd(buf2[h:], lab, h, T - h, V, ld, S, inv, 1.0, row_loss)
+    assert torch.equal(buf, buf2)
+
+
+def test_adamw_and_clip(ops):
+    n = 4096 * 3 + 64
+    g = torch.Generator().manual_seed(9)
+    p = torch.randn(n, generator=g)
+    grad = torch.randn(n, generator=g) * 0.3
+    pr, m, v = p.clone(), torch.zeros(n), torch.zeros(n)
+    pd, gd = p.clone().to(dev()), grad.to(dev())
+    md, vd = torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    sh = torch.zeros(n, dtype=torch.bfloat16, device=dev())
+    ws = torch.empty(1024, dtype=torch.float64, device=dev())
+    nc = torch.empty(2, dtype=torch.float32, device=dev())
+    for step in range(1, 4):
+        total, coef = R.clip_coef([grad], 1.0)
+        R.adamw_step(pr, grad * coef, m, v, step, 3e-4)
+        ops.grad_norm_clip(gd, 1.0, ws, nc)
+        assert abs(float(nc[0]) - float(total)) < 1e-5 * float(total)
+        assert abs(float(nc[1]) - float(coef)) < 1e-5 * float(coef)
+        ops.adamw_step(pd, gd, md, vd, sh, nc, 3e-4, 0.9, 0.95, 1e-5, 0.1, step)
+        assert rel(pd, pr) < 1e-6
+    assert rel(md, m) < 1e-5 and rel(vd, v) < 1e-5
+    assert torch.equal(sh.cpu(), bf(pd.cpu()))
+
+
+def test_cast_scale_axpy(ops):
+    n = 1000 * 8
+    x = torch.randn(n)
+    xd = x.to(dev())
+    o = torch.empty(n, dtype=torch.bfloat16, device=dev())
+    ops.cast(xd, o)
+    assert torch.equal(o.cpu(), bf(x))
+    y = torch.ones(n, device=dev())
+    a = torch.tensor(0.5, device=dev())
+    ops.axpy_(y, xd, 2.0, a)
+    assert rel(y, 1 + x) < 1e-6
+    ops.scale_bf16_(o, 1.0, a)
+    assert rel(o.float(), bf(x).float() * 0.5) < 1e-2
