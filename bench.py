@@ -1,0 +1,168 @@
+"""Headline benchmark: training tokens/s of the default decoder (bf16-mixed) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one full optimizer step of the reference's training loop (src/train.py:63-72) on one synthetic batch per
+GPU: zero_grad, forward, backward (+ overlapped RCCL gradient mean for N > 1), clip to max-norm 1.0, AdamW, LR
+schedule. Workload = BASELINE.json configs[1]: default decoder (14 layers, d 512, 8 heads x 128, I 2048, V 151936,
+tied), batch 32 x seq 2048 per GPU, token ids uniform in [3, 30000), labels = ids. Weak scaling: the per-GPU batch is
+fixed. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def train_flops_per_token(cfg, S):
+    """Algorithmic training FLOPs per token: 3 x forward; forward = 2*(block params + d*V) + L*2*S*(H*Dh)
+    (causal attention counted at half the square, tied head counted once as a GEMM, embedding gather excluded)."""
+    d, I, H, Dh, KVH, L, V = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim,
+                              cfg.num_key_value_heads, cfg.num_hidden_layers, cfg.vocab_size)
+    blocks = L * (d * (H + 2 * KVH) * Dh + H * Dh * d + 3 * d * I)
+    fwd = 2 * (blocks + d * V) + L * 2 * S * (H * Dh)
+    return 3 * fwd
+
+
+def cpu_baseline(cfg, S, seconds_budget=25.0):
+    """The reference's CPU path restated (oracle/ref_cpu.py, fp32) timed on the host cores: one training step
+    (fwd + bwd + clip + AdamW) on a bounded sample of the workload: ONE sequence of S tokens (1/32 of the GPU batch)."""
+    from oracle import ref_cpu as R
+    ocfg = R.LMConfig(**{k: getattr(cfg, k) for k in R.LMConfig.__dataclass_fields__})
+    cores = torch.get_num_threads()
+    p = R.init_params(ocfg, seed=0)
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(x) for k, x in p.items()}
+    g = torch.Generator().manual_seed(1234)
+    ids = torch.randint(3, 30000, (1, S), generator=g)
+    times = []
+    t_start = time.time()
+    for it in range(3):
+        t0 = time.time()
+        loss, grads = R.loss_and_grads(p, ocfg, ids, None, ids, "fp32")
+        _, coef = R.clip_coef(list(grads.values()), 1.0)
+        for k in p:
+            R.adamw_step(p[k], grads[k] * coef, m[k], v[k], it + 1, 5e-5)
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    best = min(times)
+    return {"value": S / best, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 sequence x {S} tokens (1/32 of the per-GPU batch), fp32, full step incl. clip+AdamW, "
+                      f"best of {len(times)} runs, {best:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from mgen import MidiLM, default_decoder, ops
+    from mgen.trainer import Trainer, init_distributed_from_env
+
+    rank, local, world = init_distributed_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
+    dev = torch.device("cuda", local)
+    cfg = default_decoder()
+    B, S = args.batch, args.seq
+    model = MidiLM(cfg, device=dev, seed=0)
+    trainer = Trainer(model, lr=5e-5, num_epochs=12, steps_per_epoch=1000, warmup=1000, max_grad_norm=1.0)
+    g = torch.Generator().manual_seed(1234 + rank)
+    ids = torch.randint(3, 30000, (B, S), generator=g).to(dev)
+    batch = {"input_ids": ids, "labels": ids}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = trainer.training_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.training_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    tokens_per_s = world * B * S * args.steps / dt
+
+    # ---- roofline of the dominant kernel: the bf16 MFMA GEMM (x @ W^T form, bf16 out) that carries the QKV, gate-up
+    # and lm_head products. One extra step with a HIP event pair around every launch of that kernel on its stream.
+    roofline = None
+    if rank == 0:
+        recs = []
+        orig = ops.gemm
+
+        def timed_gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode=ops.OUT_BF16, *rest,
+                       **kw):
+            if not trans_a and not trans_b and out_mode == ops.OUT_BF16:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                orig(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, *rest, **kw)
+                e1.record()
+                recs.append((2.0 * M * N * K, e0, e1))
+            else:
+                orig(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, *rest, **kw)
+
+        ops.gemm = timed_gemm
+        trainer.training_step(batch)
+        torch.cuda.synchronize()
+        ops.gemm = orig
+        fl = sum(r[0] for r in recs)
+        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        achieved = fl / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel<TA=0,TB=0,OUT_BF16> (QKV, gate-up, lm_head forward)",
+                    "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 4),
+                    "flops_per_launch_avg": fl / len(recs)}
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        ftok = train_flops_per_token(cfg, S)
+        out = {
+            "metric": "train tokens/s", "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "default decoder (MidiQwen shape: L14 d512 H8xDh128 I2048 V151936 tied), "
+                                   f"bf16-mixed full train step, per-GPU batch {B} x seq {S}",
+                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}"},
+            "final_loss": round(float(loss), 4),
+            "train_flops_per_token": ftok,
+            "model_tflops_per_gpu": round(tokens_per_s / world * ftok / 1e12, 1),
+            "mfma_frac_whole_step": round(tokens_per_s / world * ftok / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, S)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

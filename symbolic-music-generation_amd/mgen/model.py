@@ -75,9 +75,15 @@ def _numel(shape):
 def _register(root: nn.Module, dotted: str, param: nn.Parameter):
     parts = dotted.split(".")
     mod = root
-    for p in parts[:-1]:
+    for i, p in enumerate(parts[:-1]):
         if p not in mod._modules:
-            mod.add_module(p, nn.Module())
+            if isinstance(mod, nn.ModuleList):
+                while len(mod) <= int(p):
+                    mod.append(nn.Module())
+            else:
+                # a container whose children are numbered (model.layers.N) is a ModuleList, as in HF models
+                numbered = i + 1 < len(parts) - 1 and parts[i + 1].isdigit()
+                mod.add_module(p, nn.ModuleList() if numbered else nn.Module())
         mod = mod._modules[p]
     mod.register_parameter(parts[-1], param)
 

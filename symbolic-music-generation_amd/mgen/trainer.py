@@ -1,0 +1,102 @@
+"""Minimal trainer reproducing the arithmetic slice of the reference's `lightning.Trainer` configuration
+(/root/reference/src/train.py:63-72): bf16-mixed forward/backward, gradient clipping to max-norm 1.0, AdamW with the
+warm-up/decay schedule stepped every optimizer step, and data-parallel gradient averaging when launched with one
+process per GPU (what Lightning's DDP strategy does implicitly).
+
+Data parallelism on MI355X: each rank owns a full replica; the only exchange is the mean of the fp32 gradients.
+MidiLM keeps all gradients in one flat buffer and finishes them in contiguous ranges (head, layers L-1..0, embedding),
+so each range is handed to RCCL as ONE large all-reduce the moment backward has produced it (few, large collectives
+suit point-to-point xGMI links), on RCCL's own stream, overlapping the rest of backward. The optimizer waits for
+the outstanding reductions only.
+"""
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .optim import get_optim
+
+
+class GradReducer:
+    """Bucketed, overlapped gradient mean over the data-parallel group."""
+
+    def __init__(self, model, group=None, min_bucket_elems: int = 4 * 1024 * 1024):
+        self.model = model
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.min_bucket = min_bucket_elems
+        self._pending = []
+        self._open: Optional[list] = None  # [start, end) of the bucket being grown (ranges arrive high -> low)
+        self._ranges = {tag: (s, e) for tag, s, e in model.grad_ranges()}
+        # RCCL averages in the collective; gloo (CPU rehearsal of the same logic) has no AVG: sum, then divide
+        self._native_avg = self.world > 1 and dist.get_backend(group) == "nccl"
+        if self.world > 1:
+            model._grad_hook = self._on_range_done
+
+    def _flush(self):
+        if self._open is None:
+            return
+        s, e = self._open
+        self._open = None
+        buf = self.model.flat_grad[s:e]
+        op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
+        self._pending.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf))
+
+    def _on_range_done(self, tag):
+        s, e = self._ranges[tag]
+        if self._open is not None and self._open[0] == e:
+            self._open[0] = s          # ranges are adjacent and arrive in descending address order
+        else:
+            self._flush()
+            self._open = [s, e]
+        if self._open[1] - self._open[0] >= self.min_bucket or tag == "embed":
+            self._flush()
+
+    def wait(self):
+        self._flush()
+        for w, buf in self._pending:
+            w.wait()
+            if not self._native_avg:
+                buf.div_(self.world)
+        self._pending.clear()
+
+
+class Trainer:
+    """fit-loop pieces: `training_step(batch)` = zero_grad, forward, backward (+ overlapped all-reduce), clip,
+    AdamW, scheduler step. `batch` is a dict with input_ids / labels (/ attention_mask) on the device."""
+
+    def __init__(self, model, lr=5e-5, num_epochs=12, steps_per_epoch=1000, warmup=1000, max_grad_norm=1.0,
+                 group=None):
+        self.model = model
+        self.opt, self.sched = get_optim(model, lr, num_epochs, steps_per_epoch, warmup, max_grad_norm=max_grad_norm)
+        self.reducer = GradReducer(model, group)
+
+    def training_step(self, batch):
+        self.opt.zero_grad()
+        loss = self.model(**batch).loss
+        loss.backward()
+        self.reducer.wait()
+        self.opt.step()
+        self.sched.step()
+        return loss.detach()
+
+    @torch.no_grad()
+    def validation_step(self, batch):
+        loss = self.model(**batch).loss
+        if self.reducer.world > 1:  # self.log(..., sync_dist=True): mean over ranks
+            dist.all_reduce(loss, op=dist.ReduceOp.AVG, group=self.reducer.group)
+        return loss
+
+
+def init_distributed_from_env():
+    """One process per GPU, rendezvous from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
