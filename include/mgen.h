@@ -119,6 +119,32 @@ int mgen_scale_f32(float* x, long n, float s, mgen_stream_t stream);
 int mgen_axpy_f32(float* y, const float* x, long n, float a, const float* a_dev, mgen_stream_t stream);
 int mgen_scale_bf16(void* x, long n, float a, const float* a_dev, mgen_stream_t stream);
 
+/* ---- KV-cache decode ----------------------------------------------------------------------------------------
+ * The cache is pre-allocated [B][KVH][max_len][D] bf16 per layer (the reference grows it with torch.cat per token:
+ * DynamicLayer.update, TF cache_utils.py:127-146). mgen_kv_append copies n_new tokens per stream from token-major
+ * projection outputs (k_src/v_src [B*n_new][ld], heads at h*D) to positions pos0[b] .. pos0[b]+n_new-1. */
+int mgen_kv_append(const void* k_src, const void* v_src, long ld_k, long ld_v, void* k_cache, void* v_cache,
+                   const int* pos0, int B, int n_new, int KVH, int D, int max_len, mgen_stream_t stream);
+/* single-query attention over the cache (TF models/qwen3/modeling_qwen3.py:259-279 with q_len = 1): q [B][ld_q],
+ * out [B][ld_o] bf16, kv_len[b] keys per stream; nsplit > 1 splits the keys over workgroups and needs
+ * mgen_attn_decode_workspace(B, H, D, nsplit) floats of workspace. */
+long mgen_attn_decode_workspace(int B, int H, int D, int nsplit);
+int mgen_attn_decode(const void* q, long ld_q, const void* k_cache, const void* v_cache, const int* kv_len, void* out,
+                     long ld_o, float* workspace, int B, int H, int KVH, int D, int max_len, int nsplit, float scale,
+                     mgen_stream_t stream);
+
+/* ---- sampler -------------------------------------------------------------------------------------------------
+ * GenerationMixin._sample token selection (TF generation/utils.py:2894-2925) with the warpers
+ * TF generation/logits_process.py:301-303 (temperature), :590-595 (top-k), :527-539 (top-p), in that order.
+ * logits [B][ld] bf16 or fp32; do_sample = 0 -> argmax. The multinomial draw is argmax(p_i / q_i) over explicit
+ * Exp(1) noise: noise [B][ld_noise] fp32, or null = Philox4x32-10(seed, offset), which mgen_philox_exponential
+ * writes out for checking. out[B] int64; out2 (may be null) gets the same ids at out2[b * out2_stride]. */
+int mgen_sample(const void* logits, long ld, int B, int V, int is_bf16, int do_sample, float temperature, int top_k,
+                float top_p, const float* noise, long ld_noise, unsigned long long seed, unsigned long long offset,
+                long* out, long* out2, long out2_stride, mgen_stream_t stream);
+int mgen_philox_exponential(float* out, long ld, int B, int V, unsigned long long seed, unsigned long long offset,
+                            mgen_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

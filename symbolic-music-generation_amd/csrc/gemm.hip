@@ -18,7 +18,8 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
 
-enum OutMode { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_F32_RESID_BF16ROUND = 3, OUT_F32_RESID = 4 };
+enum OutMode { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_F32_RESID_BF16ROUND = 3, OUT_F32_RESID = 4,
+               OUT_F32_ATOMIC = 5 /* internal: split-K form of OUT_F32_ACC */ };
 
 struct GemmArgs {
     const bf16* A;
@@ -29,6 +30,7 @@ struct GemmArgs {
     long lda, ldb, ldc, ldr;
     float alpha;
     int nbm, nbn;
+    int splitk, kper;  // K is cut into `splitk` slices of `kper` elements (kper % BK == 0)
 };
 
 // ---- global -> register staging of one operand tile (4 x 16 bytes per thread) -----------------------------
@@ -82,7 +84,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware, grouped tile order: 8 row-tiles share the sweep over the column tiles
     const int nwg = g.nbm * g.nbn;
-    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int wid = xcd_remap(blockIdx.x, nwg * g.splitk);
+    const int wg = wid / g.splitk;
+    const int kbeg = (wid % g.splitk) * g.kper;
+    const int kend = min(g.K, kbeg + g.kper);
     constexpr int GROUP = 8;
     const int width = GROUP * g.nbn;
     const int grp = wg / width;
@@ -102,9 +107,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     u32x4 sa[4], sb[4];
-    const int nk = (g.K + BK - 1) / BK;
-    load_tile<TA>(sa, g.A, g.lda, m0, 0, g.M, g.K, tid);
-    load_tile<TB>(sb, g.B, g.ldb, n0, 0, g.N, g.K, tid);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    load_tile<TA>(sa, g.A, g.lda, m0, kbeg, g.M, kend, tid);
+    load_tile<TB>(sb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);
     store_tile<TA>(sa, smem, tid);
     store_tile<TB>(sb, smem + TILE_BYTES, tid);
     __syncthreads();
@@ -112,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<TA>(sa, g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
-            load_tile<TB>(sb, g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+            load_tile<TA>(sa, g.A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
+            load_tile<TB>(sb, g.B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
         }
         const char* ta = smem + cur * 2 * TILE_BYTES;
         const char* tb = ta + TILE_BYTES;
@@ -126,10 +131,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             for (int j = 0; j < 2; ++j) fb[j] = load_frag<TB>(tb, wn + 32 * j, ks, lane);
             // D[row = n][col = m]: the B-side fragment is the MFMA's A operand, so that each lane ends up with
             // 4 consecutive n of one output row m (vector stores along the contiguous dimension of C).
+            // The atomic (split-K) epilogue wants the opposite: D[row = m][col = n] puts 32 consecutive n of one
+            // row on 32 consecutive lanes, i.e. two 128-byte segments per atomic wave-instruction.
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = (MODE == OUT_F32_ATOMIC) ? mfma32(fa[i], fb[j], acc[i][j])
+                                                         : mfma32(fb[j], fa[i], acc[i][j]);
         }
         if (kt + 1 < nk) {
             char* na = smem + (cur ^ 1) * 2 * TILE_BYTES;
@@ -139,6 +148,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
+    if (MODE == OUT_F32_ATOMIC) {
+        float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn + 32 * j + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm + 32 * i + acc_row(r, lane);
+                    if (m < g.M && n < g.N) atomicAdd(C + (long)m * g.ldc + n, acc[i][j][r] * g.alpha);
+                }
+            }
+        return;
+    }
     // ---- epilogue: lane holds, per tile, m = lane&31 and n = 8*g4 + 4*(lane>>5) + e (g4 = 0..3, e = 0..3)
     const int h = lane >> 5;
 #pragma unroll
@@ -188,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
 template <bool TA, bool TB>
 int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
-    const dim3 grid(g.nbm * g.nbn), block(256);
+    const dim3 grid(g.nbm * g.nbn * g.splitk), block(256);
     const size_t lds = 4 * TILE_BYTES;
     switch (mode) {
         case OUT_BF16: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_BF16>), grid, block, lds, s, g); break;
@@ -198,6 +222,7 @@ int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
             hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID_BF16ROUND>), grid, block, lds, s, g);
             break;
         case OUT_F32_RESID: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID>), grid, block, lds, s, g); break;
+        case OUT_F32_ATOMIC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ATOMIC>), grid, block, lds, s, g); break;
         default: mgen_set_error("mgen_gemm_bf16: unknown out_mode %d", mode); return MGEN_EINVAL;
     }
     return mgen_check_launch("mgen_gemm_bf16");
@@ -228,7 +253,25 @@ extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void*
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.R = (const float*)resid;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.nbm = (M + BM - 1) / BM; g.nbn = (N + BN - 1) / BN;
-    MGEN_REQUIRE((long)g.nbm * g.nbn < (1L << 31), "mgen_gemm_bf16: grid too large");
+    MGEN_REQUIRE(out_mode >= 0 && out_mode <= OUT_F32_RESID, "mgen_gemm_bf16: unknown out_mode %d", out_mode);
+    g.splitk = 1;
+    g.kper = ((K + BK - 1) / BK) * BK;
+    // An accumulating product with few output tiles and a long reduction (weight gradients: K = tokens) is cut
+    // along K so that the chip is filled; the slices add their tiles with fp32 atomics.
+    const long tiles = (long)g.nbm * g.nbn;
+    if (out_mode == OUT_F32_ACC && tiles < 512) {
+        const int ksteps = (K + BK - 1) / BK;
+        int want = (int)((1024 + tiles - 1) / tiles);
+        int maxsplit = ksteps / 8;  // at least 8 K steps (512 reduction indices) per slice
+        int sk = want < maxsplit ? want : maxsplit;
+        if (sk > 1) {
+            const int steps_per = (ksteps + sk - 1) / sk;
+            g.kper = steps_per * BK;
+            g.splitk = (ksteps + steps_per - 1) / steps_per;
+            out_mode = OUT_F32_ATOMIC;
+        }
+    }
+    MGEN_REQUIRE(tiles * g.splitk < (1L << 31), "mgen_gemm_bf16: grid too large");
     if (!transA && !transB) return launch_mode<false, false>(g, out_mode, stream);
     if (!transA && transB) return launch_mode<false, true>(g, out_mode, stream);
     if (transA && !transB) return launch_mode<true, false>(g, out_mode, stream);

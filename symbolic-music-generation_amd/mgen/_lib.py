@@ -5,7 +5,7 @@ caller gets an exception.
 """
 import ctypes
 import os
-from ctypes import c_void_p as P, c_int as I, c_long as L, c_float as F
+from ctypes import c_void_p as P, c_int as I, c_long as L, c_float as F, c_ulonglong as U64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgen_hip.so")
@@ -33,6 +33,10 @@ SIGNATURES = {
     "mgen_scale_f32": [P, L, F, P],
     "mgen_axpy_f32": [P, P, L, F, P, P],
     "mgen_scale_bf16": [P, L, F, P, P],
+    "mgen_kv_append": [P, P, L, L, P, P, P, I, I, I, I, I, P],
+    "mgen_attn_decode": [P, L, P, P, P, P, L, P, I, I, I, I, I, I, F, P],
+    "mgen_sample": [P, L, I, I, I, I, F, I, F, P, L, U64, U64, P, P, L, P],
+    "mgen_philox_exponential": [P, L, I, I, U64, U64, P],
 }
 
 _lib = None
@@ -58,6 +62,8 @@ def lib():
         l.mgen_last_error.argtypes = []
         l.mgen_version.restype = ctypes.c_int
         l.mgen_sumsq_partial_count.restype = ctypes.c_int
+        l.mgen_attn_decode_workspace.argtypes = [I, I, I, I]
+        l.mgen_attn_decode_workspace.restype = ctypes.c_long
         l.mgen_device_info.argtypes = [I, ctypes.c_char_p, I]
         l.mgen_device_info.restype = ctypes.c_int
         _lib = l

@@ -1,0 +1,181 @@
+"""Autoregressive sampling for MidiLM: `generate()` with a pre-allocated KV cache.
+
+Call surface of the reference's sampling sites (`model.model.generate(input_ids, max_new_tokens | max_length,
+do_sample, temperature, top_k, top_p, pad_token_id, eos_token_id, use_cache)`, /root/reference/src/test_tokenizer.py:
+129-136 and notebooks/test.ipynb), i.e. transformers' GenerationMixin._sample (generation/utils.py:2783-2941):
+prefill the prompt, then one token per iteration; temperature -> top-k -> top-p -> multinomial, or argmax; finished
+rows are padded with pad_token_id; returns int64 [B, prompt + new]. As in transformers, `do_sample=True` without an
+explicit top_k runs with top_k = 50.
+
+MI355X design: the cache is allocated once per call ([B, KVH, max_len, D] bf16 per layer, head-major so that a
+stream's keys are contiguous), every step runs M = B token rows through the same GEMM kernels as training plus the
+split-key decode-attention kernel, and the sampler kernel writes the new ids straight into the output matrix. The
+multinomial draw uses explicit Exp(1) noise (argmax p/q): a `noise` tensor [steps, B, V] for parity checks, or a
+counter-based Philox stream keyed by `seed` (offset = step).
+"""
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class KVCache:
+    def __init__(self, cfg, batch: int, max_len: int, device):
+        self.max_len = max_len
+        shape = (batch, cfg.num_key_value_heads, max_len, cfg.head_dim)
+        self.k = [torch.empty(shape, dtype=torch.bfloat16, device=device) for _ in range(cfg.num_hidden_layers)]
+        self.v = [torch.empty(shape, dtype=torch.bfloat16, device=device) for _ in range(cfg.num_hidden_layers)]
+        self.zero_pos = torch.zeros(batch, dtype=torch.int32, device=device)
+
+    def bytes_per_token(self):
+        return 2 * len(self.k) * self.k[0].shape[1] * self.k[0].shape[3] * 2
+
+
+class _DecodeBuffers:
+    def __init__(self, cfg, B, dev):
+        bf, f32 = torch.bfloat16, torch.float32
+        d, I = cfg.hidden_size, cfg.intermediate_size
+        H, KVH, Dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.h0 = torch.empty(B, d, dtype=f32, device=dev)
+        self.h1 = torch.empty(B, d, dtype=f32, device=dev)
+        self.h2 = torch.empty(B, d, dtype=f32, device=dev)
+        self.x = torch.empty(B, d, dtype=bf, device=dev)
+        self.qkv = torch.empty(B, cfg.qkv_width, dtype=bf, device=dev)
+        self.qk = torch.empty(B, (H + KVH) * Dh, dtype=bf, device=dev)
+        self.att = torch.empty(B, H * Dh, dtype=bf, device=dev)
+        self.gu = torch.empty(B, 2 * I, dtype=bf, device=dev)
+        self.act = torch.empty(B, I, dtype=bf, device=dev)
+        self.ldv = (cfg.vocab_size + 7) // 8 * 8
+        self.logits = torch.empty(B, self.ldv, dtype=bf, device=dev)
+        self.next = torch.empty(B, dtype=torch.int64, device=dev)
+
+
+class GenerationMixin:
+    """Mixed into MidiLM."""
+
+    def _decode_split(self, B, length):
+        cfg = self.cfg
+        blocks = B * cfg.num_attention_heads
+        want = max(1, 1024 // max(blocks, 1))
+        return max(1, min(64, want, (length + 255) // 256))
+
+    def _decode_step(self, tokens, cache: KVCache, t: int, buf: _DecodeBuffers, lens, ws):
+        """One token per stream at position t (all streams share t); returns bf16 logits [B, ldv]."""
+        cfg = self.cfg
+        B = tokens.shape[0]
+        d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                            cfg.intermediate_size)
+        NQ, QK = cfg.qkv_width, (H + KVH) * Dh
+        cs = self._rope_table(t + 1)
+        scale = Dh ** -0.5
+        pos = lens[t]          # int32 [B] = t
+        kv_len = lens[t + 1]   # int32 [B] = t + 1
+        nsplit = self._decode_split(B, t + 1)
+        h = buf.h0
+        ops.embedding_fwd(tokens, self.model.embed_tokens.weight, h, self._err_flag)
+        for l, v in enumerate(self._layers):
+            ops.rmsnorm_fwd(h, v.w_ln1, buf.x, None, cfg.rms_norm_eps)
+            ops.linear_fwd(buf.x, v.s_qkv, buf.qkv)
+            qp = buf.qk.data_ptr()
+            ops.qknorm_rope_fwd(buf.qkv, NQ, qp, qp + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, 1, B, H, KVH, Dh,
+                                cfg.rms_norm_eps)
+            ops.kv_append(qp + 2 * H * Dh, buf.qkv.data_ptr() + 2 * QK, QK, NQ, cache.k[l], cache.v[l], pos, B, 1, KVH,
+                          Dh, cache.max_len)
+            ops.attn_decode(qp, QK, cache.k[l], cache.v[l], kv_len, buf.att, H * Dh, ws, B, H, KVH, Dh, cache.max_len,
+                            nsplit, scale)
+            ops.linear_fwd(buf.att, v.s_o, buf.h1, ops.OUT_F32_RESID_BF16ROUND, h)
+            ops.rmsnorm_fwd(buf.h1, v.w_ln2, buf.x, None, cfg.rms_norm_eps)
+            ops.linear_fwd(buf.x, v.s_gu, buf.gu)
+            ops.swiglu_fwd(buf.gu, buf.act)
+            nxt = buf.h2 if h is buf.h0 else buf.h0
+            ops.linear_fwd(buf.act, v.s_down, nxt, ops.OUT_F32_RESID_BF16ROUND, buf.h1)
+            h = nxt
+        ops.rmsnorm_fwd(h, self.model.norm.weight, buf.x, None, cfg.rms_norm_eps)
+        W = self._view(self.flat_shadow, self._lm_head_name())
+        ops.gemm(buf.x, W, buf.logits, B, cfg.vocab_size, d, d, W.stride(0), buf.ldv)
+        return buf.logits
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, max_new_tokens: Optional[int] = None, max_length: Optional[int] = None,
+                 do_sample: bool = False, temperature: float = 1.0, top_k: Optional[int] = None, top_p: float = 1.0,
+                 pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None, use_cache: bool = True,
+                 noise: Optional[torch.Tensor] = None, seed: int = 0, eos_check_every: int = 16,
+                 return_step_logits: bool = False, **unused):
+        if input_ids is None or input_ids.dim() != 2:
+            raise ValueError("generate() needs input_ids of shape [batch, prompt_len]")
+        if not input_ids.is_cuda:
+            raise RuntimeError("MidiLM runs on the GPU only: input_ids must be a CUDA/HIP tensor")
+        cfg = self.cfg
+        B, P = input_ids.shape
+        if max_new_tokens is None:
+            max_new_tokens = (max_length if max_length is not None else 20) - P
+        if max_new_tokens <= 0:
+            return input_ids.clone()
+        if do_sample:
+            if not (isinstance(temperature, (int, float)) and temperature > 0):
+                raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")
+            if top_k is None:
+                top_k = 50  # transformers' generation default whenever sampling is on
+            if top_k is not None and top_k < 0:
+                raise ValueError(f"`top_k` has to be a non-negative integer, but is {top_k}")
+            if not (0 < top_p <= 1.0):
+                raise ValueError(f"`top_p` has to be a float > 0 and <= 1, but is {top_p}")
+        if eos_token_id is not None and pad_token_id is None:
+            pad_token_id = eos_token_id
+        dev = input_ids.device
+        V = cfg.vocab_size
+        total = P + max_new_tokens
+        self.sync_shadow()
+        out = torch.empty(B, total, dtype=torch.int64, device=dev)
+        out[:, :P] = input_ids
+        cache = KVCache(cfg, B, total, dev)
+        buf = _DecodeBuffers(cfg, B, dev)
+        # lens[t] = int32 [B] filled with t: per-stream positions / key counts without per-step host->device traffic
+        lens = torch.arange(total + 1, dtype=torch.int32, device=dev)[:, None].expand(total + 1, B).contiguous()
+        max_split = self._decode_split(B, total)
+        ws_n = ops.attn_decode_workspace(B, cfg.num_attention_heads, cfg.head_dim, max_split)
+        ws = torch.empty(max(ws_n, 1), dtype=torch.float32, device=dev)
+        unfinished = torch.ones(B, dtype=torch.int64, device=dev) if eos_token_id is not None else None
+        step_logits = [] if return_step_logits else None
+
+        def pick(logits, step):
+            nz = noise[step] if (noise is not None and do_sample) else None
+            col = out.data_ptr() + 8 * (P + step)
+            ops.sample(logits, V, buf.next, do_sample, temperature, top_k or 0, top_p, nz, seed, step,
+                       out2=None if unfinished is not None else col, out2_stride=total)
+            if return_step_logits:
+                step_logits.append(logits[:, :V].float().clone())
+            if unfinished is not None:
+                tok = buf.next * unfinished + pad_token_id * (1 - unfinished)
+                buf.next.copy_(tok)
+                out[:, P + step] = tok
+                unfinished.mul_((tok != eos_token_id).long())
+
+        # ---- prefill: the training forward on the prompt, K/V written into the cache
+        xN, _ = self._run_layers(input_ids.contiguous(), save=None, cache=cache)
+        last = xN.view(B, P, -1)[:, -1, :].contiguous()
+        W = self._view(self.flat_shadow, self._lm_head_name())
+        ops.gemm(last, W, buf.logits, B, V, cfg.hidden_size, last.stride(0), W.stride(0), buf.ldv)
+        pick(buf.logits, 0)
+        n_done = 1
+        for step in range(1, max_new_tokens):
+            if unfinished is not None and step % eos_check_every == 0 and int(unfinished.max()) == 0:
+                break
+            logits = self._decode_step(buf.next, cache, P + step - 1, buf, lens, ws)
+            pick(logits, step)
+            n_done = step + 1
+        if unfinished is not None and n_done < max_new_tokens:
+            out = out[:, :P + n_done]
+        if unfinished is not None:
+            # trim trailing columns produced after every row had finished (the reference stops at that point)
+            fin = (out[:, P:] == eos_token_id).long().cumsum(1).clamp(max=1)
+            all_done = fin.min(0).values
+            if bool(all_done.any()):
+                first = int(torch.nonzero(all_done)[0])
+                out = out[:, :P + first + 1]
+        if self._err_flag is not None and int(self._err_flag) != 0:
+            raise IndexError("token id out of range in generate()")
+        if return_step_logits:
+            return out, torch.stack(step_logits, 0)
+        return out

@@ -23,6 +23,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import LMConfig
+from .generation import GenerationMixin
 
 _ALIGN = 64  # every tensor starts at a multiple of 64 elements in the flat buffers
 
@@ -93,7 +94,7 @@ class _LayerViews:
     pass
 
 
-class MidiLM(nn.Module):
+class MidiLM(GenerationMixin, nn.Module):
     def __init__(self, cfg: LMConfig, device="cuda", seed: Optional[int] = 0, compute_dtype=torch.bfloat16):
         super().__init__()
         if compute_dtype != torch.bfloat16:
@@ -272,7 +273,7 @@ class MidiLM(nn.Module):
         ops.gemm(hN, W, buf, T, V, cfg.hidden_size, hN.stride(0), W.stride(0), ld)
         return buf[:, :V]
 
-    def _run_layers(self, input_ids, save: Optional[list], pos: Optional[torch.Tensor] = None):
+    def _run_layers(self, input_ids, save: Optional[list], pos: Optional[torch.Tensor] = None, cache=None):
         cfg = self.cfg
         B, S = input_ids.shape
         T = B * S
@@ -296,6 +297,9 @@ class MidiLM(nn.Module):
             qk = torch.empty(T, QK, dtype=bf, device=dev)
             ops.qknorm_rope_fwd(qkv, NQ, qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, S,
                                 T, H, KVH, Dh, cfg.rms_norm_eps)
+            if cache is not None:  # prefill: rotated keys and values of every prompt position go into the cache
+                ops.kv_append(qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK, QK, NQ, cache.k[l], cache.v[l],
+                              cache.zero_pos, B, S, KVH, Dh, cache.max_len)
             att = torch.empty(T, H * Dh, dtype=bf, device=dev)
             lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
             ops.attn_fwd(qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK, att.data_ptr(), lse,

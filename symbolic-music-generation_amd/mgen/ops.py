@@ -153,5 +153,35 @@ def axpy_(y, x, a=1.0, a_dev=None):
     call("mgen_axpy_f32", _p(y), _p(x), x.numel(), a, _p(a_dev), _stream())
 
 
+def kv_append(k_src, v_src, ld_k, ld_v, k_cache, v_cache, pos0, B, n_new, KVH, D, max_len):
+    """k_src/v_src are raw device pointers of token-major rows; caches are [B, KVH, max_len, D] bf16 tensors."""
+    call("mgen_kv_append", k_src, v_src, ld_k, ld_v, _p(k_cache), _p(v_cache), _p(pos0), B, n_new, KVH, D, max_len,
+         _stream())
+
+
+def attn_decode(q, ld_q, k_cache, v_cache, kv_len, out, ld_o, workspace, B, H, KVH, D, max_len, nsplit, scale):
+    call("mgen_attn_decode", q, ld_q, _p(k_cache), _p(v_cache), _p(kv_len), _p(out), ld_o, _p(workspace), B, H, KVH, D,
+         max_len, nsplit, scale, _stream())
+
+
+def attn_decode_workspace(B, H, D, nsplit):
+    from ._lib import lib
+    return lib().mgen_attn_decode_workspace(B, H, D, nsplit)
+
+
+def sample(logits, V, out, do_sample=False, temperature=1.0, top_k=0, top_p=1.0, noise=None, seed=0, offset=0,
+           out2=None, out2_stride=0):
+    """logits [B, ld] (bf16 or fp32) -> out [B] int64; out2 = raw pointer of an optional strided second destination."""
+    B = logits.shape[0]
+    call("mgen_sample", _p(logits), logits.stride(0), B, V, int(logits.dtype == torch.bfloat16), int(do_sample),
+         float(temperature), int(top_k or 0), float(top_p), _p(noise), noise.stride(0) if noise is not None else 0,
+         int(seed), int(offset), _p(out), out2 or 0, out2_stride, _stream())
+
+
+def philox_exponential(out, V, seed, offset):
+    B = out.shape[0]
+    call("mgen_philox_exponential", _p(out), out.stride(0), B, V, int(seed), int(offset), _stream())
+
+
 def scale_bf16_(x, a=1.0, a_dev=None):
     call("mgen_scale_bf16", _p(x), x.numel(), a, _p(a_dev), _stream())

@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     from mgen import _lib
     declared = set(header_functions())
-    bound = set(_lib.SIGNATURES) | {"mgen_last_error", "mgen_version", "mgen_sumsq_partial_count", "mgen_device_info"}
+    bound = set(_lib.SIGNATURES) | {"mgen_last_error", "mgen_version", "mgen_sumsq_partial_count", "mgen_device_info",
+                                     "mgen_attn_decode_workspace"}
     assert declared == bound, (declared - bound, bound - declared)
 
 

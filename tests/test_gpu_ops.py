@@ -65,6 +65,27 @@ def test_gemm_layouts(ops, ta, tb, M, N, K):
     assert rel(out, res.cpu() + bf(ref).float()) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 8192), (512, 1024, 4096 + 64), (100, 72, 5000)])
+def test_gemm_weight_gradient_split_k(ops, M, N, K):
+    """dW[M,N] += dY[K,M]^T X[K,N] with few output tiles and a long reduction: the split-K (atomic) path."""
+    g = torch.Generator().manual_seed(K)
+    A = bf(torch.randn(K, M, generator=g) * 0.5)
+    B = bf(torch.randn(K, N, generator=g) * 0.5)
+    ref = A.float().t() @ B.float()
+    ldm, ldn = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    a_st = torch.zeros(K, ldm, dtype=torch.bfloat16)
+    a_st[:, :M] = A
+    b_st = torch.zeros(K, ldn, dtype=torch.bfloat16)
+    b_st[:, :N] = B
+    a_st, b_st = a_st.to(dev()), b_st.to(dev())
+    prev = torch.randn(M, N, generator=g)
+    c = prev.clone().to(dev())
+    ops.gemm(a_st, b_st, c, M, N, K, ldm, ldn, N, True, True, ops.OUT_F32_ACC)
+    assert rel(c, prev + ref) < 1e-5
+    ops.gemm(a_st, b_st, c, M, N, K, ldm, ldn, N, True, True, ops.OUT_F32_ACC)
+    assert rel(c, prev + 2 * ref) < 1e-5
+
+
 def test_gemm_exact_identity_asymmetric(ops):
     """A = I against an asymmetric integer B: catches swapped rows/columns and a wrong k order exactly."""
     n = 128
