@@ -64,8 +64,33 @@ def cpu_baseline(cfg, S, seconds_budget=25.0):
                       f"best of {len(times)} runs, {best:.2f} s/step"}
 
 
+def bench_decode(model, cfg, streams, new_tokens, dev):
+    """Batched sampling (BASELINE.json configs[3] shape): `streams` concurrent KV-cache decode streams, prompt = one
+    BOS token, temperature 0.97, top-p 0.95, no top-k, EOS disabled, Philox noise seed 1234. Reported per GPU."""
+    prompt = torch.full((streams, 1), cfg.bos_token_id, dtype=torch.int64, device=dev)
+    kw = dict(do_sample=True, temperature=0.97, top_k=0, top_p=0.95, seed=1234)
+    model.generate(prompt, max_new_tokens=8, **kw)  # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.generate(prompt, max_new_tokens=new_tokens, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    steps = new_tokens
+    L, KVH, Dh = cfg.num_hidden_layers, cfg.num_key_value_heads, cfg.head_dim
+    kv_tok = 2 * L * KVH * Dh * 2
+    weights = 2 * (sum(p.numel() for p in model.parameters()))
+    ctx_sum = sum(range(1, steps + 1))  # keys read at step t = t (prompt of 1 token)
+    bytes_total = steps * (weights + streams * cfg.vocab_size * 2) + streams * ctx_sum * kv_tok
+    return {"streams": streams, "new_tokens": new_tokens, "tokens_per_s_per_gpu": round(streams * steps / dt, 1),
+            "ms_per_step": round(dt / steps * 1e3, 3), "algorithmic_GBps": round(bytes_total / dt / 1e9, 1),
+            "hbm_frac": round(bytes_total / dt / 1e9 / PEAK_HBM_GBS, 4),
+            "sampling": "T=0.97 top_p=0.95 top_k=off philox(seed 1234)", "out_shape": list(out.shape)}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--decode-streams", type=int, default=256)
+    ap.add_argument("--decode-tokens", type=int, default=256, help="0 disables the decode measurement")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
@@ -112,7 +137,7 @@ def main():
     # ---- roofline of the dominant kernel: the bf16 MFMA GEMM (x @ W^T form, bf16 out) that carries the QKV, gate-up
     # and lm_head products. One extra step with a HIP event pair around every launch of that kernel on its stream.
     roofline = None
-    if rank == 0:
+    if True:  # every rank runs the extra step (it contains collectives for N > 1); rank 0 reports
         recs = []
         orig = ops.gemm
 
@@ -157,6 +182,11 @@ def main():
             "mfma_frac_whole_step": round(tokens_per_s / world * ftok / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": roofline,
         }
+        if world == 1 and args.decode_tokens > 0:
+            del trainer, batch
+            model.zero_grad()
+            torch.cuda.empty_cache()
+            out["decode"] = bench_decode(model, cfg, args.decode_streams, args.decode_tokens, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(out))
