@@ -15,6 +15,7 @@
 // on the lane (S^T = K Q^T in fwd/dQ), so row max / row sum need one cross-half exchange only, and the fp32 score
 // tile is re-used in place as the bf16 operand of the next product (no LDS round trip for P or dS).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -53,6 +54,23 @@ __device__ __forceinline__ void tile_store(const u32x4 (&st)[4], char* lds, int 
     }
 }
 
+// The same 64 x 128 tile straight into its LDS image by LDS-DMA (no staging registers, no ds_write): a wave
+// instruction fills one contiguous 1 KiB piece (4 rows), so the image's chunk swizzle goes on the source address.
+__device__ __forceinline__ void tile_glds(const bf16* __restrict__ base, long tok_stride, long tok0, int row0, int S,
+                                          char* lds, int tid) {
+    const int wave = tid >> 6, l = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j;
+        const int row = piece * 4 + (l >> 4);
+        const int ch = (l & 15) ^ swz256(row);
+        const int gr = min(row0 + row, S - 1);
+        const bf16* src = base + (tok0 + gr) * tok_stride + ch * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + piece * 1024), 16, 0, 0);
+    }
+}
+
 // rows of this wave as B-operand fragments: lane (r, hh) holds row (row0 + r), columns 16ks + 8hh .. +7
 __device__ __forceinline__ void load_own_rows(bf16x8 (&f)[8], const bf16* __restrict__ base, long tok_stride,
                                               long tok0, int row0, int S, int lane) {
@@ -60,6 +78,16 @@ __device__ __forceinline__ void load_own_rows(bf16x8 (&f)[8], const bf16* __rest
     const bf16* p = base + (tok0 + gr) * tok_stride + 8 * (lane >> 5);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) f[ks] = *reinterpret_cast<const bf16x8*>(p + 16 * ks);
+}
+
+// The register-resident operand rows are loaded once, before the main loop. Drain those loads here and pass the
+// registers through an empty asm so that the compiler's wait-count bookkeeping no longer ties the loop's MFMAs to
+// vector-memory loads: otherwise every MFMA of the first phase waits for the NEXT tile's prefetch loads issued just
+// before it, and the prefetch hides nothing.
+__device__ __forceinline__ void settle_frags(bf16x8 (&f)[8]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(f[i]));
 }
 
 __device__ __forceinline__ void zero16(f32x16& a) {
@@ -109,82 +137,89 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const int last_key = min(q0 + 127, S - 1);
     const int ntiles = last_key / 64 + 1;
 
-    u32x4 sk[4], sv[4];
-    tile_load(sk, Kb, a.sk, tok0, 0, S, tid);
-    tile_load(sv, Vb, a.sv, tok0, 0, S, tid);
-    tile_store(sk, smem, tid);
-    tile_store(sv, smem + TILE, tid);
+    tile_glds(Kb, a.sk, tok0, 0, S, smem, tid);
+    tile_glds(Vb, a.sv, tok0, 0, S, smem + TILE, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    settle_frags(qf);
 
     for (int j = 0; j < ntiles; ++j) {
         const int cur = j & 1;
         const int kv0 = j * 64;
-        if (j + 1 < ntiles) {
-            tile_load(sk, Kb, a.sk, tok0, kv0 + 64, S, tid);
-            tile_load(sv, Vb, a.sv, tok0, kv0 + 64, S, tid);
+        if (j + 1 < ntiles) {  // next tile into the other buffer (last read one iteration ago, before a barrier)
+            char* nb = smem + (cur ^ 1) * 2 * TILE;
+            tile_glds(Kb, a.sk, tok0, kv0 + 64, S, nb, tid);
+            tile_glds(Vb, a.sv, tok0, kv0 + 64, S, nb + TILE, tid);
         }
         const char* Kt = smem + cur * 2 * TILE;
         const char* Vt = Kt + TILE;
         if (kv0 <= qw0 + 31) {  // wave-uniform: this wave has at least one visible key in the tile
-            f32x16 s[2];
+            // MASKED is a compile-time flag: only tiles that straddle the diagonal pay for the key > query test
+            auto tile = [&](auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
+                f32x16 s[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                zero16(s[t]);
+                for (int t = 0; t < 2; ++t) {
+                    zero16(s[t]);
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) s[t] = mfma32(frag_row_img256(Kt, 32 * t, ks, lane), qf[ks], s[t]);
-            }
-            const bool need_mask = kv0 + 63 > qw0;
-            float mx = NEG_BIG;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = s[t][r] * sl2;
-                    if (need_mask) {
-                        const int key = kv0 + 32 * t + acc_row(r, lane);
-                        if (key > my_q) v = NEG_BIG;
-                    }
-                    s[t][r] = v;
-                    mx = fmaxf(mx, v);
+                    for (int ks = 0; ks < 8; ++ks)
+                        s[t] = mfma32(frag_row_img256(Kt, 32 * t, ks, lane), qf[ks], s[t]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - m_new);
-            m = m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = fast_exp2(s[t][r] - m_new);
-                    s[t][r] = p;
-                    psum += p;
-                }
-            l = l * alpha + psum;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-            bf16x8 pf[2][2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                pf[t][0] = acc_to_frag<0>(s[t]);
-                pf[t][1] = acc_to_frag<1>(s[t]);
-            }
-            // O^T[d][q] += V^T[d][key] * P^T[key][q]
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
+                // running max in the RAW score domain (the scale is positive); the scale is folded into the
+                // exponent's fma below
+                float mx = NEG_BIG;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2)
-                        o[db] = mfma32(frag_col_img256<true>(Vt, 32 * t + 16 * s2, 32 * db, lane), pf[t][s2], o[db]);
+                    for (int r = 0; r < 16; ++r) {
+                        if (MASKED) {
+                            const int key = kv0 + 32 * t + acc_row(r, lane);
+                            if (key > my_q) s[t][r] = NEG_BIG;
+                        }
+                        mx = fmaxf(mx, s[t][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (__any(mx > m)) {  // wave-uniform; when no row's max grew the rescale factor is exactly 1
+                    const float m_new = fmaxf(m, mx);
+                    const float alpha = fast_exp2((m - m_new) * sl2);
+                    m = m_new;
+                    l *= alpha;
+#pragma unroll
+                    for (int db = 0; db < 4; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                }
+                const float nm = -m * sl2;
+                float psum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = fast_exp2(__builtin_fmaf(s[t][r], sl2, nm));
+                        s[t][r] = p;
+                        psum += p;
+                    }
+                l += psum;
+                bf16x8 pf[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    pf[t][0] = acc_to_frag<0>(s[t]);
+                    pf[t][1] = acc_to_frag<1>(s[t]);
+                }
+                // O^T[d][q] += V^T[d][key] * P^T[key][q]
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2)
+                            o[db] = mfma32(frag_col_img256<true>(Vt, 32 * t + 16 * s2, 32 * db, lane), pf[t][s2],
+                                           o[db]);
+            };
+            if (kv0 + 63 > qw0) tile(std::true_type{});
+            else tile(std::false_type{});
         }
-        if (j + 1 < ntiles) {
-            char* nb = smem + (cur ^ 1) * 2 * TILE;
-            tile_store(sk, nb, tid);
-            tile_store(sv, nb + TILE, tid);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
@@ -192,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     if (my_q < S) {
         const float inv = 1.f / lt;
         store_rows_T(o, a.Out + (tok0 + my_q) * a.so + (long)h * D, inv, lane);
-        if (lane < 32 && a.LSE) a.LSE[((long)b * a.H + h) * S + my_q] = (m + __log2f(lt)) * LN2;
+        if (lane < 32 && a.LSE) a.LSE[((long)b * a.H + h) * S + my_q] = (m * sl2 + __log2f(lt)) * LN2;
     }
 }
 
@@ -251,19 +286,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int last_key = min(q0 + 127, S - 1);
     const int ntiles = last_key / 64 + 1;
 
-    u32x4 sk[4], sv[4];
-    tile_load(sk, Kb, a.sk, tok0, 0, S, tid);
-    tile_load(sv, Vb, a.sv, tok0, 0, S, tid);
-    tile_store(sk, smem, tid);
-    tile_store(sv, smem + TILE, tid);
+    tile_glds(Kb, a.sk, tok0, 0, S, smem, tid);
+    tile_glds(Vb, a.sv, tok0, 0, S, smem + TILE, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    settle_frags(qf);
+    settle_frags(dof);
 
     for (int j = 0; j < ntiles; ++j) {
         const int cur = j & 1;
         const int kv0 = j * 64;
-        if (j + 1 < ntiles) {
-            tile_load(sk, Kb, a.sk, tok0, kv0 + 64, S, tid);
-            tile_load(sv, Vb, a.sv, tok0, kv0 + 64, S, tid);
+        if (j + 1 < ntiles) {  // next tile into the other buffer (last read one iteration ago, before a barrier)
+            char* nb = smem + (cur ^ 1) * 2 * TILE;
+            tile_glds(Kb, a.sk, tok0, kv0 + 64, S, nb, tid);
+            tile_glds(Vb, a.sv, tok0, kv0 + 64, S, nb + TILE, tid);
         }
         const char* Kt = smem + cur * 2 * TILE;
         const char* Vt = Kt + TILE;
@@ -280,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 for (int ks = 0; ks < 8; ++ks) dp = mfma32(frag_row_img256(Vt, 32 * t, ks, lane), dof[ks], dp);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float p = fast_exp2(s[r] * sl2 - lse2);
+                    float p = fast_exp2(__builtin_fmaf(s[r], sl2, -lse2));
                     if (need_mask) {
                         const int key = kv0 + 32 * t + acc_row(r, lane);
                         if (key > my_q) p = 0.f;
@@ -296,11 +332,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 }
             }
         }
-        if (j + 1 < ntiles) {
-            char* nb = smem + (cur ^ 1) * 2 * TILE;
-            tile_store(sk, nb, tid);
-            tile_store(sv, nb + TILE, tid);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if (my_q < S) store_rows_T(dq, a.dQ + (tok0 + my_q) * a.sdq + (long)h * D, a.scale, lane);
@@ -340,14 +372,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int per_head = t_end - t_first;
     const int nsteps = per_head * group;
 
-    u32x4 sq[4], sdo[4];
     float s_lse = 0.f, s_delta = 0.f;
 
-    auto issue = [&](int step) {
+    auto issue = [&](int step, int buf) {
         const int hq = kvh * group + step / per_head;
         const int qt0 = (t_first + step % per_head) * 64;
-        tile_load(sq, a.Q + (long)hq * D, a.sq, tok0, qt0, S, tid);
-        tile_load(sdo, a.dO + (long)hq * D, a.sdo, tok0, qt0, S, tid);
+        char* base = smem + buf * DKV_BUF;
+        tile_glds(a.Q + (long)hq * D, a.sq, tok0, qt0, S, base, tid);
+        tile_glds(a.dO + (long)hq * D, a.sdo, tok0, qt0, S, base + TILE, tid);
         if (tid < 64) {
             const int q = min(qt0 + tid, S - 1);
             const long o = ((long)b * a.H + hq) * S + q;
@@ -357,67 +389,72 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     };
     auto commit = [&](int buf) {
         char* base = smem + buf * DKV_BUF;
-        tile_store(sq, base, tid);
-        tile_store(sdo, base + TILE, tid);
         if (tid < 64) {
             reinterpret_cast<float*>(base + 2 * TILE)[tid] = s_lse;
             reinterpret_cast<float*>(base + 2 * TILE + 256)[tid] = s_delta;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
-    issue(0);
+    issue(0, 0);
     commit(0);
     __syncthreads();
+    settle_frags(kf);
+    settle_frags(vf);
 
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < nsteps) issue(step + 1);
+        if (step + 1 < nsteps) issue(step + 1, cur ^ 1);
         const int qt0 = (t_first + step % per_head) * 64;
         const char* Qt = smem + cur * DKV_BUF;
         const char* dOt = Qt + TILE;
         const float* lse_s = reinterpret_cast<const float*>(Qt + 2 * TILE);
         const float* del_s = lse_s + 64;
         if (qt0 + 63 >= kw0) {  // wave-uniform: some query of the tile can see some key of this wave
-            const bool need_mask = qt0 < kw0 + 31 || qt0 + 63 >= S;
+            auto tile = [&](auto masked) {
+                constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x16 s, dp;
-                zero16(s);
-                zero16(dp);
+                for (int u = 0; u < 2; ++u) {
+                    f32x16 s, dp;
+                    zero16(s);
+                    zero16(dp);
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) s = mfma32(frag_row_img256(Qt, 32 * u, ks, lane), kf[ks], s);
+                    for (int ks = 0; ks < 8; ++ks) s = mfma32(frag_row_img256(Qt, 32 * u, ks, lane), kf[ks], s);
 #pragma unroll
-                for (int ks = 0; ks < 8; ++ks) dp = mfma32(frag_row_img256(dOt, 32 * u, ks, lane), vf[ks], dp);
-                // s[reg]: query = qt0 + 32u + acc_row(reg), key = my_k
-                f32x16 ds;
+                    for (int ks = 0; ks < 8; ++ks) dp = mfma32(frag_row_img256(dOt, 32 * u, ks, lane), vf[ks], dp);
+                    // s[reg]: query = qt0 + 32u + acc_row(reg), key = my_k
+                    f32x16 ds;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int qr = 32 * u + 8 * g4 + 4 * (lane >> 5);
-                    const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qr);
-                    const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + qr);
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int qr = 32 * u + 8 * g4 + 4 * (lane >> 5);
+                        const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qr);
+                        const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + qr);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g4 + e;
-                        float p = fast_exp2(s[r] * sl2 - lv[e]);
-                        if (need_mask) {
-                            const int q = qt0 + qr + e;
-                            if (my_k > q || q >= S) p = 0.f;
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g4 + e;
+                            float p = fast_exp2(__builtin_fmaf(s[r], sl2, -lv[e]));
+                            if (MASKED) {
+                                const int q = qt0 + qr + e;
+                                if (my_k > q || q >= S) p = 0.f;
+                            }
+                            s[r] = p;
+                            ds[r] = p * (dp[r] - dl[e]);
                         }
-                        s[r] = p;
-                        ds[r] = p * (dp[r] - dl[e]);
+                    }
+                    const bf16x8 p0 = acc_to_frag<0>(s), p1 = acc_to_frag<1>(s);
+                    const bf16x8 d0 = acc_to_frag<0>(ds), d1 = acc_to_frag<1>(ds);
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) {
+                        // dV^T[d][key] += dO^T[d][q] * P[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
+                        dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u, 32 * db, lane), p0, dv[db]);
+                        dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u + 16, 32 * db, lane), p1, dv[db]);
+                        dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u, 32 * db, lane), d0, dk[db]);
+                        dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u + 16, 32 * db, lane), d1, dk[db]);
                     }
                 }
-                const bf16x8 p0 = acc_to_frag<0>(s), p1 = acc_to_frag<1>(s);
-                const bf16x8 d0 = acc_to_frag<0>(ds), d1 = acc_to_frag<1>(ds);
-#pragma unroll
-                for (int db = 0; db < 4; ++db) {
-                    // dV^T[d][key] += dO^T[d][q] * P[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
-                    dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u, 32 * db, lane), p0, dv[db]);
-                    dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u + 16, 32 * db, lane), p1, dv[db]);
-                    dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u, 32 * db, lane), d0, dk[db]);
-                    dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u + 16, 32 * db, lane), d1, dk[db]);
-                }
-            }
+            };
+            if (qt0 < kw0 + 31 || qt0 + 63 >= S) tile(std::true_type{});
+            else tile(std::false_type{});
         }
         if (step + 1 < nsteps) commit(cur ^ 1);
         __syncthreads();
@@ -482,4 +519,14 @@ extern "C" int mgen_attn_bwd(const void* q, const void* k, const void* v, const 
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((S + 127) / 128, KVH, B), block, 2 * DKV_BUF, stream, a);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((S + 127) / 128, H, B), block, 4 * TILE, stream, a);
     return mgen_check_launch("mgen_attn_bwd");
+}
+
+// Diagnostic: resident workgroups per CU the runtime predicts for the attention kernels (0 fwd, 1 dq, 2 dkv).
+extern "C" int mgen_debug_attn_occupancy(int which) {
+    int n = -1;
+    hipError_t e;
+    if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_fwd_kernel, 256, 4 * TILE);
+    else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dq_kernel, 256, 4 * TILE);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_kernel, 256, 2 * DKV_BUF);
+    return e == hipSuccess ? n : -(int)e;
 }

@@ -69,6 +69,33 @@ __device__ __forceinline__ void store_tile(const u32x4 (&st)[4], char* lds, int 
     }
 }
 
+// ---- global -> LDS directly (LDS-DMA, 16 bytes per lane): a wave instruction fills one contiguous 1 KiB piece of
+// the tile image, so the XOR swizzle of the image is applied to each lane's SOURCE address. No zero fill: used when
+// K is a multiple of the K step; rows/columns beyond the matrix edge are clamped (they feed outputs never stored).
+template <bool MC>
+__device__ __forceinline__ void glds_tile(const bf16* __restrict__ P, long ld, int row0, int k0, int nrows,
+                                          char* lds_tile, int tid) {
+    const int wave = tid >> 6, l = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j;
+        const bf16* src;
+        if (!MC) {
+            const int row = piece * 8 + (l >> 3);
+            const int ch = (l & 7) ^ ((row >> 1) & 7);
+            const int gr = min(row0 + row, nrows - 1);
+            src = P + (long)gr * ld + k0 + ch * 8;
+        } else {
+            const int kr = piece * 4 + (l >> 4);
+            const int ch = (l & 15) ^ swz256(kr);
+            const int gc = min(row0 + ch * 8, ((nrows - 1) >> 3) << 3);
+            src = P + (long)(k0 + kr) * ld + gc;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds_tile + piece * 1024), 16, 0, 0);
+    }
+}
+
 // fragment for output rows/cols [o0, o0+32) and k-step ks (16 reduction indices) of the current tile
 template <bool MC>
 __device__ __forceinline__ bf16x8 load_frag(const char* tile, int o0, int ks, int lane) {
@@ -76,8 +103,10 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int o0, int ks, in
     return frag_col_img256<false>(tile, 16 * ks, o0, lane);
 }
 
-template <bool TA, bool TB, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+// GLDS = true: single 32 KiB LDS image filled by LDS-DMA, two barriers per K step, up to 4 workgroups per CU cover
+// each other's load latency. GLDS = false: register-staged, zero-filling variant for K not a multiple of 64.
+template <bool TA, bool TB, int MODE, bool GLDS>
+__global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // buffer b: A tile at smem + b*2*TILE_BYTES, B tile right behind it
 
@@ -106,8 +135,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 sa[4], sb[4];
     const int nk = (kend - kbeg + BK - 1) / BK;
+    if (GLDS) {
+        for (int kt = 0; kt < nk; ++kt) {
+            glds_tile<TA>(g.A, g.lda, m0, kbeg + kt * BK, g.M, smem, tid);
+            glds_tile<TB>(g.B, g.ldb, n0, kbeg + kt * BK, g.N, smem + TILE_BYTES, tid);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = load_frag<TA>(smem, wm + 32 * i, ks, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = load_frag<TB>(smem + TILE_BYTES, wn + 32 * j, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = (MODE == OUT_F32_ATOMIC) ? mfma32(fa[i], fb[j], acc[i][j])
+                                                             : mfma32(fb[j], fa[i], acc[i][j]);
+            }
+            __syncthreads();
+        }
+    } else {
+    u32x4 sa[4], sb[4];
     load_tile<TA>(sa, g.A, g.lda, m0, kbeg, g.M, kend, tid);
     load_tile<TB>(sb, g.B, g.ldb, n0, kbeg, g.N, kend, tid);
     store_tile<TA>(sa, smem, tid);
@@ -147,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
+    }
 
     if (MODE == OUT_F32_ATOMIC) {
         float* C = reinterpret_cast<float*>(g.C);
@@ -163,8 +216,92 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             }
         return;
     }
-    // ---- epilogue: lane holds, per tile, m = lane&31 and n = 8*g4 + 4*(lane>>5) + e (g4 = 0..3, e = 0..3)
     const int h = lane >> 5;
+    if (MODE == OUT_BF16 && (g.ldc & 7) == 0) {
+        // bf16 output through LDS: the wave parks its 64x64 sub-tile in its own 8 KiB of the (now idle) staging
+        // area as [64 rows][128 bytes] with the 16-byte chunks XOR-swizzled by row, then writes whole 128-byte row
+        // segments with 16 bytes per lane (8 store instructions per lane instead of 32 scattered 8-byte ones).
+        char* st = smem + wave * 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int row = 32 * i + (lane & 31);
+                    const int ch = 4 * j + g4;
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][j][4 * g4 + e] * g.alpha);
+                    *reinterpret_cast<bf16x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4) + 8 * h) = o;
+                }
+        // same wave wrote and reads: no workgroup barrier needed, only the LDS counter
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bf16* C = reinterpret_cast<bf16*>(g.C);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3), ch = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4));
+            const int m = m0 + wm + row, n = n0 + wn + ch * 8;
+            if (m < g.M) {
+                bf16* c = C + (long)m * g.ldc + n;
+                if (n + 7 < g.N) {
+                    *reinterpret_cast<u32x4*>(c) = v;
+                } else {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < g.N) c[e] = b[e];
+                }
+            }
+        }
+        return;
+    }
+    if (MODE != OUT_BF16 && (g.ldc & 3) == 0 && (g.N & 3) == 0 &&
+        ((MODE != OUT_F32_RESID_BF16ROUND && MODE != OUT_F32_RESID) || (g.ldr & 3) == 0)) {
+        // fp32 output through LDS, 32 rows at a time: [32 rows][256 bytes] per wave, 16-byte chunks XOR-swizzled by
+        // row; then whole 256-byte row segments are combined with the old value / residual and stored, 16 B per lane.
+        char* st = smem + wave * 8192;
+        float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int row = lane & 31;
+                    const int ch = 8 * j + 2 * g4 + h;
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g4 + e] * g.alpha;
+                    *reinterpret_cast<f32x4*>(st + row * 256 + ((ch ^ (row & 15)) << 4)) = o;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4), ch = lane & 15;
+                f32x4 v = *reinterpret_cast<const f32x4*>(st + row * 256 + ((ch ^ (row & 15)) << 4));
+                const int m = m0 + wm + 32 * i + row, n = n0 + wn + ch * 4;
+                if (m < g.M && n < g.N) {
+                    float* c = C + (long)m * g.ldc + n;
+                    if (MODE == OUT_F32_RESID_BF16ROUND || MODE == OUT_F32_RESID) {
+                        const f32x4 r = *reinterpret_cast<const f32x4*>(g.R + (long)m * g.ldr + n);
+                        if (MODE == OUT_F32_RESID_BF16ROUND) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
+                        }
+                        v += r;
+                    } else if (MODE == OUT_F32_ACC) {
+                        v += *reinterpret_cast<const f32x4*>(c);
+                    }
+                    *reinterpret_cast<f32x4*>(c) = v;
+                }
+            }
+        }
+        return;
+    }
+    // ---- generic epilogue: lane holds, per tile, m = lane&31 and n = 8*g4 + 4*(lane>>5) + e (g4 = 0..3, e = 0..3)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm + 32 * i + (lane & 31);
@@ -210,19 +347,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool GLDS>
 int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
     const dim3 grid(g.nbm * g.nbn * g.splitk), block(256);
-    const size_t lds = 4 * TILE_BYTES;
+    const size_t lds = (GLDS ? 2 : 4) * TILE_BYTES;
     switch (mode) {
-        case OUT_BF16: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_BF16>), grid, block, lds, s, g); break;
-        case OUT_F32: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32>), grid, block, lds, s, g); break;
-        case OUT_F32_ACC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ACC>), grid, block, lds, s, g); break;
+        case OUT_BF16: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_BF16, GLDS>), grid, block, lds, s, g); break;
+        case OUT_F32: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32, GLDS>), grid, block, lds, s, g); break;
+        case OUT_F32_ACC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ACC, GLDS>), grid, block, lds, s, g); break;
         case OUT_F32_RESID_BF16ROUND:
-            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID_BF16ROUND>), grid, block, lds, s, g);
+            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID_BF16ROUND, GLDS>), grid, block, lds, s, g);
             break;
-        case OUT_F32_RESID: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID>), grid, block, lds, s, g); break;
-        case OUT_F32_ATOMIC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ATOMIC>), grid, block, lds, s, g); break;
+        case OUT_F32_RESID: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID, GLDS>), grid, block, lds, s, g); break;
+        case OUT_F32_ATOMIC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ATOMIC, GLDS>), grid, block, lds, s, g); break;
         default: mgen_set_error("mgen_gemm_bf16: unknown out_mode %d", mode); return MGEN_EINVAL;
     }
     return mgen_check_launch("mgen_gemm_bf16");
@@ -261,7 +398,7 @@ extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void*
     const long tiles = (long)g.nbm * g.nbn;
     if (out_mode == OUT_F32_ACC && tiles < 512) {
         const int ksteps = (K + BK - 1) / BK;
-        int want = (int)((1024 + tiles - 1) / tiles);
+        int want = (int)(1024 / tiles);  // 4 workgroups per CU x 256 CUs resident at once: fill them in ONE round
         int maxsplit = ksteps / 8;  // at least 8 K steps (512 reduction indices) per slice
         int sk = want < maxsplit ? want : maxsplit;
         if (sk > 1) {
@@ -272,8 +409,12 @@ extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void*
         }
     }
     MGEN_REQUIRE(tiles * g.splitk < (1L << 31), "mgen_gemm_bf16: grid too large");
-    if (!transA && !transB) return launch_mode<false, false>(g, out_mode, stream);
-    if (!transA && transB) return launch_mode<false, true>(g, out_mode, stream);
-    if (transA && !transB) return launch_mode<true, false>(g, out_mode, stream);
-    return launch_mode<true, true>(g, out_mode, stream);
+    const bool glds = (K % BK) == 0;
+#define MGEN_GEMM_GO(TA_, TB_) \
+    return glds ? launch_mode<TA_, TB_, true>(g, out_mode, stream) : launch_mode<TA_, TB_, false>(g, out_mode, stream)
+    if (!transA && !transB) MGEN_GEMM_GO(false, false);
+    if (!transA && transB) MGEN_GEMM_GO(false, true);
+    if (transA && !transB) MGEN_GEMM_GO(true, false);
+    MGEN_GEMM_GO(true, true);
+#undef MGEN_GEMM_GO
 }

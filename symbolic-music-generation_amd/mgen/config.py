@@ -24,7 +24,9 @@ class LMConfig:
     bos_token_id: int = 1
     eos_token_id: int = 2
     pad_token_id: int = 0
-    lm_head_chunk_tokens: int = 8192   # rows of logits alive at once in the fused lm_head + cross-entropy
+    # rows of logits alive at once in the fused lm_head + cross-entropy (32768 x 151936 bf16 = 10 GB; large chunks
+    # give the dgrad GEMM, whose output is only [chunk, d], enough tiles to fill 256 CUs)
+    lm_head_chunk_tokens: int = 32768
 
     def to_dict(self):
         return asdict(self)
