@@ -18,11 +18,11 @@ def _cfg(ocfg):
     return LMConfig(**{k: getattr(ocfg, k) for k in R.LMConfig.__dataclass_fields__})
 
 
-@pytest.fixture(scope="module")
-def tiny():
+@pytest.fixture(scope="module", params=list(CASES))
+def tiny(request):
     from mgen import MidiLM
-    ocfg = CASES["tiny_qwen3"]
-    g = load("tiny_qwen3")
+    ocfg = CASES[request.param]
+    g = load(request.param)
     p = tiny_params(ocfg)
     m = MidiLM(_cfg(ocfg), device="cuda:0", seed=None)
     m.load_state_dict(p)
@@ -90,10 +90,11 @@ def test_padded_batch_loss(tiny):
             assert rel_err(slim(gq), g[k]) < BF16_TOL, name
 
 
-def test_training_steps_follow_reference_curve():
+@pytest.mark.parametrize("case", list(CASES))
+def test_training_steps_follow_reference_curve(case):
     from mgen import MidiLM, get_optim
-    ocfg = CASES["tiny_qwen3"]
-    g = load("tiny_qwen3")
+    ocfg = CASES[case]
+    g = load(case)
     m = MidiLM(_cfg(ocfg), device="cuda:0", seed=None)
     m.load_state_dict(tiny_params(ocfg))
     ids = torch.from_numpy(g["input_ids"]).cuda()

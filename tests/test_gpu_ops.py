@@ -227,9 +227,10 @@ def _attn_ref(q, k, v, scale):
     return o  # [B,S,H*D]
 
 
-@pytest.mark.parametrize("B,S,H,KVH", [(1, 128, 1, 1), (2, 200, 2, 2), (1, 384, 4, 2), (2, 64, 2, 1), (1, 777, 1, 1)])
-def test_attention_fwd_bwd(ops, B, S, H, KVH):
-    D = 128
+@pytest.mark.parametrize("B,S,H,KVH,D", [(1, 128, 1, 1, 128), (2, 200, 2, 2, 128), (1, 384, 4, 2, 128),
+                                         (2, 64, 2, 1, 128), (1, 777, 1, 1, 128), (2, 200, 4, 4, 64),
+                                         (1, 384, 2, 2, 64), (1, 64, 6, 6, 64), (1, 1000, 2, 2, 64)])
+def test_attention_fwd_bwd(ops, B, S, H, KVH, D):
     g = torch.Generator().manual_seed(B * 1000 + S + H)
     T = B * S
     q = bf(torch.randn(B, S, H, D, generator=g))
