@@ -30,6 +30,20 @@ def tiny_params(cfg):
     return params
 
 
+TINY_POS4D = R.LMConfig(vocab_size=1, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=2, head_dim=128, tie_word_embeddings=False)
+
+
+def tiny_params_pos4d(cfg=TINY_POS4D):
+    from oracle import ref_pos4d as P
+    params = P.init_params_pos4d(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    for k in params:
+        if "norm" in k:
+            params[k] = 1.0 + 0.1 * torch.randn(params[k].shape, generator=g)
+    return params
+
+
 def checksum(params):
     return float(sum(v.double().abs().sum() for v in params.values()))
 

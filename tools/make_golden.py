@@ -234,8 +234,168 @@ def full_dq_case():
     print("dq_full_c1 loss", out["loss"], "gnorm", out["grad_norm"])
 
 
+def load_reference_pos4d():
+    """Import the reference's own 4-D model module (the only in-tree arithmetic of the reference) and pull the two
+    post-processing functions out of generate_music.py without importing that script (its top-level imports need
+    packages that are absent here). `wandb` is absent too: a stub with a no-op log() takes its place."""
+    import ast
+    import importlib.machinery
+    import types
+    import transformers.activations  # noqa: F401
+    import transformers.modeling_utils  # noqa: F401
+    if "wandb" not in sys.modules:
+        w = types.ModuleType("wandb")
+        w.__spec__ = importlib.machinery.ModuleSpec("wandb", None)
+        w.log = lambda *a, **k: None
+        sys.modules["wandb"] = w
+    sys.path.insert(0, "/root/reference")
+    from src.model import modeling as ref_modeling
+    from src.model import config as ref_config
+    tree = ast.parse(open("/root/reference/generate_music.py").read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("f2", "process_last_logits")]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "generate_music.py", "exec"), ns)
+    return ref_modeling, ref_config, ns["process_last_logits"]
+
+
+def synth_notes(gen, B, S, pad_tail=()):
+    """Batches in the layout of MidiDataset4D (/root/reference/src/train_model_new.py:23-47,114-158): rows
+    [start s, duration s, pitch, velocity], a [0,0,0,0] row first, labels = next row with the start replaced by the
+    start delta, the last label = the last row with delta 0; padded tails repeat [last start, 0, 2, 0] and carry
+    -100 labels."""
+    pos = torch.zeros(B, S, 4)
+    lab = torch.zeros(B, S, 4)
+    mask = torch.ones(B, S, dtype=torch.long)
+    for b in range(B):
+        n_pad = pad_tail[b] if b < len(pad_tail) else 0
+        n = S - n_pad
+        delta = torch.empty(n - 1).exponential_(4.0, generator=gen)
+        delta[torch.rand(n - 1, generator=gen) < 0.3] = 0.0   # chords: equal start times
+        start = torch.cat([torch.zeros(1), delta.cumsum(0)])
+        dur = 0.05 + 2.0 * torch.rand(n, generator=gen)
+        pitch = torch.randint(21, 109, (n,), generator=gen).float()
+        vel = torch.randint(1, 128, (n,), generator=gen).float()
+        rows = torch.stack([start, dur, pitch, vel], dim=1)
+        rows[0] = 0.0
+        if n_pad:
+            rows = torch.cat([rows, torch.tensor([float(rows[-1, 0]), 0.0, 2.0, 0.0]).repeat(n_pad, 1)], dim=0)
+            mask[b, n:] = 0
+        l = torch.cat([rows[1:].clone(), rows[-1:].clone()], dim=0)
+        l[:, 0] = l[:, 0] - rows[:, 0]
+        if n_pad:
+            l[n:] = -100
+        pos[b], lab[b] = rows, l
+    return pos, lab, mask
+
+
+POS4D_GRAD_KEYS = ["lm_head.weight", "model.layers.0.self_attn.q_proj.weight",
+                   "model.layers.0.self_attn.k_proj.weight", "model.layers.0.self_attn.v_proj.weight",
+                   "model.layers.0.self_attn.o_proj.weight", "model.layers.0.self_attn.q_norm.weight",
+                   "model.layers.0.self_attn.k_norm.weight", "model.layers.0.input_layernorm.weight",
+                   "model.layers.0.mlp.gate_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.norm.weight"]
+
+
+def pos4d_case(name="tiny_pos4d", B=2, S=128):
+    from oracle import ref_pos4d as P
+    ref_modeling, ref_config, ref_process_last = load_reference_pos4d()
+    cfg = R.LMConfig(vocab_size=1, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                     num_attention_heads=2, num_key_value_heads=2, head_dim=128, tie_word_embeddings=False)
+    params = P.init_params_pos4d(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    for k in params:
+        if "norm" in k:
+            params[k] = 1.0 + 0.1 * torch.randn(params[k].shape, generator=g)
+
+    def build():
+        hc = ref_config.Qwen3Config(vocab_size=1, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                                    num_hidden_layers=cfg.num_hidden_layers,
+                                    num_attention_heads=cfg.num_attention_heads,
+                                    num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+                                    max_position_embeddings=4096, rms_norm_eps=cfg.rms_norm_eps,
+                                    pad_token_id=0, bos_token_id=0, eos_token_id=0)
+        hc.pad_token_id = 0
+        m = ref_modeling.Qwen3ForCausalLM(hc)
+        missing, unexpected = m.load_state_dict(params, strict=True)
+        return m.train()
+
+    causal = {"full_attention": None}   # "already prepared" mask mapping: plain causal attention
+    m = build()
+    gen = torch.Generator().manual_seed(2468)
+    pos, lab, mask = synth_notes(gen, B, S, pad_tail=(0, 37))
+    out = {"seed_params": 0, "seed_norm": 7, "param_checksum": checksum(params), "position_tensors": pos.numpy(),
+           "labels": lab.numpy(), "attention_mask": mask.numpy()}
+
+    m.zero_grad()
+    o = m(position_tensors=pos, labels=lab, attention_mask=causal)
+    o.loss.backward()
+    out["fp32_loss"] = o.loss.item()
+    out["fp32_pred"] = o.logits.detach().numpy()
+    gr = grads_of(m)
+    for k in POS4D_GRAD_KEYS:
+        out["fp32_grad/" + k] = gr[k].numpy()
+    out["fp32_grad_norm"] = torch.linalg.vector_norm(
+        torch.stack([torch.linalg.vector_norm(g_) for g_ in gr.values()])).item()
+    out["encoding_of_labels"] = ref_modeling._compute_encoding(lab[:, :S - 37]).numpy()
+    out["rope_angles"] = m.model.rot_pos_emb(pos).detach().numpy()[:, ::8]
+
+    # all labels masked -> constant zero loss
+    o = m(position_tensors=pos, labels=torch.full_like(lab, -100.0), attention_mask=causal)
+    out["all_masked_loss"] = float(o.loss)
+
+    # bf16 autocast on the CPU (torch.norm of the head output runs in bf16 there, in fp32 on a GPU)
+    m.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o = m(position_tensors=pos, labels=lab, attention_mask=causal)
+    o.loss.backward()
+    out["bf16_loss"] = o.loss.item()
+    out["bf16_pred"] = o.logits.detach().float().numpy()
+    gr = grads_of(m)
+    for k in POS4D_GRAD_KEYS:
+        out["bf16_grad/" + k] = gr[k].float().numpy()
+
+    # 14 steps of clip(5.0) + AdamW + schedule (src/train_model_new.py:372-378: lr 5e-4, clip 5.0)
+    m = build()
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-4, weight_decay=0.1, betas=(0.9, 0.95), eps=1e-5)
+    warm = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1e-6, end_factor=1.0, total_iters=10)
+    dec = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.1, total_iters=12 * 20 - 10)
+    sch = torch.optim.lr_scheduler.SequentialLR(opt, [warm, dec], milestones=[10])
+    lrs, losses = [], []
+    for step in range(14):
+        m.zero_grad()
+        o = m(position_tensors=pos, labels=lab, attention_mask=causal)
+        o.loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 5.0)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+        losses.append(o.loss.item())
+    out["train_lrs"], out["train_losses"] = np.array(lrs), np.array(losses)
+    sd = m.state_dict()
+    for k in ("lm_head.weight", "model.layers.0.self_attn.q_proj.weight", "model.norm.weight"):
+        out["after14/" + k] = sd[k].detach().numpy().copy()
+
+    # generate_music loop (generate_music.py:165-179) on the seeded weights: 48 notes, prefix re-run every step
+    m = build().eval()
+    generated = pos[0:1, 0:1, :]
+    preds = []
+    with torch.no_grad():
+        for i in range(48):
+            o = m(input_ids=None, position_tensors=generated, attention_mask=causal)
+            preds.append(o.logits[0, i].clone())
+            nxt = ref_process_last(o.logits[0, i, :, :], device="cpu")
+            nxt[0, 0, 0] += generated[0, -1, 0]
+            generated = torch.cat([generated, nxt], dim=1)
+    out["gen_rows"] = generated[0].numpy()
+    out["gen_preds"] = torch.stack(preds, 0).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "fp32 loss", out["fp32_loss"], "bf16 loss", out["bf16_loss"], "last loss", losses[-1])
+
+
 if __name__ == "__main__":
     print("transformers", transformers.__version__, "torch", torch.__version__)
+    if "--pos4d-only" in sys.argv:
+        pos4d_case()
+        sys.exit(0)
     tiny_q = R.LMConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                         num_attention_heads=2, num_key_value_heads=2, head_dim=128)
     tiny_case("tiny_qwen3", tiny_q, hf_qwen3)
