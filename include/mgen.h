@@ -65,6 +65,40 @@ int mgen_qknorm_rope_bwd(const void* dqk, long ld_in, void* dq_raw, void* dk_raw
                          const float* cos_sin, const int* pos, int S, long T, int HQ, int HK, int D, float eps,
                          int is_bf16, mgen_stream_t stream);
 
+/* ---- 4-D position model: adjacent-pair rotary embedding from continuous note coordinates ------------------------
+ * Replaces Qwen3Model.rot_pos_emb (reference src/model/modeling.py:498-545): cos_sin[t][a*(D/8)+j] =
+ * (cos, sin)(pos4[t][a] * freqs[j]) for the 4 axes a and D/8 frequencies j (the caller passes the reference's
+ * frequency vector: D/8-4 values theta^(-2j/D) followed by 4 zeros). pos4 [T][4] fp32, cos_sin [T][D/2][2] fp32. */
+int mgen_rope4d_table(const float* pos4, const float* freqs, float* cos_sin, long T, int D, mgen_stream_t stream);
+/* Replaces q_norm/k_norm + apply_rotary_pos_emb on q,k and apply_rotary_pos_emb_1 on v with the adjacent pairing
+ * (x0,x1)->(-x1,x0) (reference src/model/modeling.py:87-98,164-174,264-270). qkv [T][ld_in] holds HQ query heads,
+ * HK key heads, HV value heads of width D; q/k rows are RMS-normalised with gains wq/wk (null = no norm), v rows are
+ * only rotated. Any head count may be 0: HQ = HK = 0 is a plain rotation of HV heads by +angle. */
+int mgen_qkvnorm_rope4d_fwd(const void* qkv, long ld_in, void* qout, void* kout, void* vout, long ld_q, long ld_k,
+                            long ld_v, const float* wq, const float* wk, const float* cos_sin, long T, int HQ, int HK,
+                            int HV, int D, float eps, int is_bf16, mgen_stream_t stream);
+/* Backward of the above (outputs may alias dqkv). With HQ = HK = 0 it is the rotation by -angle, which is also the
+ * forward of apply_rotary_pos_emb_T on the attention output (reference src/model/modeling.py:176-180,300-302). */
+int mgen_qkvnorm_rope4d_bwd(const void* dqkv, long ld_in, void* dq_raw, void* dk_raw, void* dv_raw, long ld_q,
+                            long ld_k, long ld_v, const void* raw_qkv, long ld_raw, const float* wq, const float* wk,
+                            float* dwq, float* dwk, const float* cos_sin, long T, int HQ, int HK, int HV, int D,
+                            float eps, int is_bf16, mgen_stream_t stream);
+/* out[t][:] = vec[:] for every t: the constant input vector of the 4-D model (reference src/model/modeling.py:
+ * 389-394,426-428). */
+int mgen_fill_rows(const float* vec, float* out, long T, int d, mgen_stream_t stream);
+/* Cosine loss of the 4-D model (reference src/model/modeling.py:620-660 with the targets of :105-141).
+ * labels [T][4] fp32; a row counts when none of its 4 values is -100. inv_count = 1/(8*rows that count) or 0. */
+int mgen_cos4d_count(const float* labels, long T, float* inv_count, int* count, mgen_stream_t stream);
+/* pairs [T][16] (bf16 or fp32) = head output; pred_out [T][16] fp32 = unit-normalised pairs (optional);
+ * with labels: row_loss[T] = sum over the 8 pairs of 1 - <pred, target> (0 for rows that do not count), and
+ * dpairs [T][16] (type of pairs, optional) = grad_scale * d(mean loss)/d(pairs). */
+int mgen_cos4d_fwd_bwd(const void* pairs, const float* labels, const float* inv_count, float grad_scale,
+                       float* pred_out, float* row_loss, void* dpairs, long T, int is_bf16, mgen_stream_t stream);
+/* process_last_logits + the start-time accumulation of generate_music (reference generate_music.py:110-142,173-174):
+ * next[b][0..3] = note decoded from the 8 unit pairs pred[b][0..15], start = decoded delta + prev[b][0]. */
+int mgen_pos4d_next(const float* pred, long ld_pred, const float* prev, long ld_prev, float* next, long ld_next, int B,
+                    mgen_stream_t stream);
+
 /* ---- causal self-attention (bf16 MFMA, head_dim 128) ---------------------------------------------------------
  * scaled_dot_product_attention(is_causal=True, scale) — TF integrations/sdpa_attention.py:154-163, eager twin
  * TF models/qwen3/modeling_qwen3.py:185-207. q/k/v/out are token-major [B*S][heads][128] views with token strides

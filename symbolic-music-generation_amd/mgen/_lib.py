@@ -18,6 +18,13 @@ SIGNATURES = {
     "mgen_rope_table": [P, P, I, I, P],
     "mgen_qknorm_rope_fwd": [P, L, P, P, L, L, P, P, P, P, I, L, I, I, I, F, I, P],
     "mgen_qknorm_rope_bwd": [P, L, P, P, L, L, P, L, P, P, P, P, P, P, I, L, I, I, I, F, I, P],
+    "mgen_rope4d_table": [P, P, P, L, I, P],
+    "mgen_qkvnorm_rope4d_fwd": [P, L, P, P, P, L, L, L, P, P, P, L, I, I, I, I, F, I, P],
+    "mgen_qkvnorm_rope4d_bwd": [P, L, P, P, P, L, L, L, P, L, P, P, P, P, P, L, I, I, I, I, F, I, P],
+    "mgen_fill_rows": [P, P, L, I, P],
+    "mgen_cos4d_count": [P, L, P, P, P],
+    "mgen_cos4d_fwd_bwd": [P, P, P, F, P, P, P, L, I, P],
+    "mgen_pos4d_next": [P, L, P, L, P, L, I, P],
     "mgen_attn_fwd": [P, P, P, P, P, L, L, L, L, I, I, I, I, I, F, P],
     "mgen_attn_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, P],
     "mgen_swiglu_fwd": [P, P, L, I, I, P],

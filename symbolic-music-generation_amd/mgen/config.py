@@ -27,6 +27,12 @@ class LMConfig:
     # rows of logits alive at once in the fused lm_head + cross-entropy (32768 x 151936 bf16 = 10 GB; large chunks
     # give the dgrad GEMM, whose output is only [chunk, d], enough tiles to fill 256 CUs)
     lm_head_chunk_tokens: int = 32768
+    # 4-D position model (/root/reference/src/model/modeling.py): notes enter as continuous [start, duration, pitch,
+    # velocity] rows through an adjacent-pair rotary embedding of q, k AND v; no token embedding; a 16-wide head
+    # predicting 8 unit angle pairs trained with a cosine loss
+    pos4d: bool = False
+    rope4d_theta: float = 10000.0     # fixed in the reference (:510), independent of rope_theta
+    rope4d_nope: int = 4              # zero frequencies ("NoPE" pairs) at the end of each axis' block (:522-525)
 
     def to_dict(self):
         return asdict(self)
@@ -39,6 +45,12 @@ class LMConfig:
 def default_decoder() -> LMConfig:
     """The reference's default decoder (MidiQwen, src/model/model.py:120-139)."""
     return LMConfig()
+
+
+def pos4d_decoder() -> LMConfig:
+    """The reference's 4-D position model (MidiQwenNew, src/model/model.py:273-290): the default decoder's shape
+    without a vocabulary."""
+    return LMConfig(vocab_size=1, tie_word_embeddings=False, pos4d=True)
 
 
 def aria_style_llama() -> LMConfig:

@@ -49,6 +49,11 @@ class _DecodeBuffers:
         self.ldv = (cfg.vocab_size + 7) // 8 * 8
         self.logits = torch.empty(B, self.ldv, dtype=bf, device=dev)
         self.next = torch.empty(B, dtype=torch.int64, device=dev)
+        if cfg.pos4d:
+            self.rot = torch.empty(B, cfg.qkv_width, dtype=bf, device=dev)
+            self.pairs = torch.empty(B, 16, dtype=bf, device=dev)
+            self.pred = torch.empty(B, 16, dtype=f32, device=dev)
+            self.cur = torch.empty(B, 4, dtype=f32, device=dev)
 
 
 class GenerationMixin:
@@ -179,3 +184,106 @@ class GenerationMixin:
         if return_step_logits:
             return out, torch.stack(step_logits, 0)
         return out
+
+    # ------------------------------------------------------------------------------------------------
+    # 4-D position model: note-by-note generation
+    # ------------------------------------------------------------------------------------------------
+    def _decode_step4d(self, rows, cache: KVCache, t: int, buf: _DecodeBuffers, lens, ws):
+        """One note row per stream ([B,4] fp32, contiguous) at sequence index t; leaves the unit pairs in buf.pred."""
+        cfg = self.cfg
+        B = rows.shape[0]
+        d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                            cfg.intermediate_size)
+        NQ, QK = cfg.qkv_width, (H + KVH) * Dh
+        cs = self._rope4d_table(rows)
+        scale = Dh ** -0.5
+        pos, kv_len = lens[t], lens[t + 1]
+        nsplit = self._decode_split(B, t + 1)
+        h = buf.h0
+        ops.fill_rows(self.model.embed_vector, h)
+        qp = buf.rot.data_ptr()
+        kp, vp = qp + 2 * H * Dh, qp + 2 * QK
+        for l, v in enumerate(self._layers):
+            ops.rmsnorm_fwd(h, v.w_ln1, buf.x, None, cfg.rms_norm_eps)
+            ops.linear_fwd(buf.x, v.s_qkv, buf.qkv)
+            ops.qkvnorm_rope4d_fwd(buf.qkv.data_ptr(), NQ, qp, kp, vp, NQ, NQ, NQ, v.w_qn, v.w_kn, cs, B, H, KVH, KVH,
+                                   Dh, cfg.rms_norm_eps)
+            ops.kv_append(kp, vp, NQ, NQ, cache.k[l], cache.v[l], pos, B, 1, KVH, Dh, cache.max_len)
+            ops.attn_decode(qp, NQ, cache.k[l], cache.v[l], kv_len, buf.att, H * Dh, ws, B, H, KVH, Dh, cache.max_len,
+                            nsplit, scale)
+            ops.rotate4d(buf.att, buf.att, cs, B, H, Dh, inverse=True)
+            ops.linear_fwd(buf.att, v.s_o, buf.h1, ops.OUT_F32_RESID_BF16ROUND, h)
+            ops.rmsnorm_fwd(buf.h1, v.w_ln2, buf.x, None, cfg.rms_norm_eps)
+            ops.linear_fwd(buf.x, v.s_gu, buf.gu)
+            ops.swiglu_fwd(buf.gu, buf.act)
+            nxt = buf.h2 if h is buf.h0 else buf.h0
+            ops.linear_fwd(buf.act, v.s_down, nxt, ops.OUT_F32_RESID_BF16ROUND, buf.h1)
+            h = nxt
+        ops.rmsnorm_fwd(h, self.model.norm.weight, buf.x, None, cfg.rms_norm_eps)
+        W = self._view(self.flat_shadow, "lm_head.weight")
+        ops.gemm(buf.x, W, buf.pairs, B, 16, d, d, W.stride(0), 16)
+        ops.cos4d_fwd_bwd(buf.pairs, None, None, 1.0, buf.pred, None, None)
+
+    @torch.no_grad()
+    def generate_music(self, position_tensors, total_length: int = 200, use_cache: bool = True,
+                       return_preds: bool = False):
+        """Note-by-note generation of the 4-D position model (/root/reference/generate_music.py:146-179): every
+        step decodes the unit pairs predicted at the last row into [start delta, duration, pitch, velocity]
+        (process_last_logits, :116-142), adds the previous start time and appends the row.
+
+        position_tensors: fp32 [B, P, 4] starting rows (the reference starts from the single row
+        batch['position_tensors'][0:1, 0:1]). Returns fp32 [B, P + total_length, 4].
+        The reference re-runs the whole prefix for every new note; with use_cache (default) the rotated keys and
+        values stay in a pre-allocated cache and each step costs one row. use_cache=False keeps the prefix re-run."""
+        cfg = self.cfg
+        if not cfg.pos4d:
+            raise RuntimeError("generate_music() belongs to the 4-D position model (config.pos4d)")
+        if position_tensors.dim() != 3 or position_tensors.shape[-1] != 4 or position_tensors.shape[1] < 1:
+            raise ValueError("position_tensors must be [batch, prompt_len >= 1, 4]")
+        if not position_tensors.is_cuda:
+            raise RuntimeError("MidiLM runs on the GPU only: position_tensors must be a CUDA/HIP tensor")
+        dev = position_tensors.device
+        B, P = position_tensors.shape[:2]
+        total = P + total_length
+        self.sync_shadow()
+        out = torch.zeros(B, total, 4, dtype=torch.float32, device=dev)
+        out[:, :P] = position_tensors
+        preds = [] if return_preds else None
+        row_bytes, ld = 16, total * 4
+
+        def decode_into(pred, ld_pred, t):
+            """row t+1 <- note decoded from pred, start accumulated on row t"""
+            ops.pos4d_next(pred, ld_pred, out.data_ptr() + row_bytes * t, ld, out.data_ptr() + row_bytes * (t + 1),
+                           ld, B)
+
+        if not use_cache:
+            for i in range(total_length):
+                t = P + i - 1
+                xN, _ = self._run_layers(out[:, :t + 1].contiguous(), save=None)
+                last = xN.view(B, t + 1, -1)[:, -1, :].contiguous()
+                self._cos_head_loss(last, None, with_grad=False)
+                if return_preds:
+                    preds.append(self._last_pred.clone())
+                decode_into(self._last_pred.data_ptr(), 16, t)
+            return (out, torch.stack(preds, 1).view(B, -1, 8, 2)) if return_preds else out
+
+        cache = KVCache(cfg, B, total, dev)
+        buf = _DecodeBuffers(cfg, B, dev)
+        lens = torch.arange(total + 1, dtype=torch.int32, device=dev)[:, None].expand(total + 1, B).contiguous()
+        ws_n = ops.attn_decode_workspace(B, cfg.num_attention_heads, cfg.head_dim, self._decode_split(B, total))
+        ws = torch.empty(max(ws_n, 1), dtype=torch.float32, device=dev)
+        # prefill on the starting rows
+        xN, _ = self._run_layers(out[:, :P].contiguous(), save=None, cache=cache)
+        last = xN.view(B, P, -1)[:, -1, :].contiguous()
+        self._cos_head_loss(last, None, with_grad=False)
+        if return_preds:
+            preds.append(self._last_pred.clone())
+        decode_into(self._last_pred.data_ptr(), 16, P - 1)
+        for i in range(1, total_length):
+            t = P + i - 1
+            buf.cur.copy_(out[:, t])
+            self._decode_step4d(buf.cur, cache, t, buf, lens, ws)
+            if return_preds:
+                preds.append(buf.pred.clone())
+            decode_into(buf.pred.data_ptr(), 16, t)
+        return (out, torch.stack(preds, 1).view(B, -1, 8, 2)) if return_preds else out

@@ -26,6 +26,7 @@ from .config import LMConfig
 from .generation import GenerationMixin
 
 _ALIGN = 64  # every tensor starts at a multiple of 64 elements in the flat buffers
+POS4D_HEAD_OUT = 16  # 4-D position model: 8 (cos, sin) pairs (/root/reference/src/model/modeling.py:560)
 
 
 class CausalLMOutput:
@@ -45,7 +46,7 @@ class CausalLMOutput:
 def param_layout(cfg: LMConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
                         cfg.intermediate_size)
-    out = [("model.embed_tokens.weight", (cfg.vocab_size, d))]
+    out = [] if cfg.pos4d else [("model.embed_tokens.weight", (cfg.vocab_size, d))]
     for l in range(cfg.num_hidden_layers):
         p = f"model.layers.{l}."
         out.append((p + "input_layernorm.weight", (d,)))
@@ -61,7 +62,9 @@ def param_layout(cfg: LMConfig) -> List[Tuple[str, Tuple[int, ...]]]:
         out.append((p + "mlp.up_proj.weight", (I, d)))
         out.append((p + "mlp.down_proj.weight", (d, I)))
     out.append(("model.norm.weight", (d,)))
-    if not cfg.tie_word_embeddings:
+    if cfg.pos4d:
+        out.append(("lm_head.weight", (POS4D_HEAD_OUT, d)))
+    elif not cfg.tie_word_embeddings:
         out.append(("lm_head.weight", (cfg.vocab_size, d)))
     return out
 
@@ -121,7 +124,13 @@ class MidiLM(GenerationMixin, nn.Module):
             prm = nn.Parameter(self._view(self.flat_param, name), requires_grad=True)
             prm.grad = self._view(self.flat_grad, name)
             _register(self, name, prm)
-        if cfg.tie_word_embeddings:
+        if cfg.pos4d:
+            if not cfg.qk_norm or cfg.tie_word_embeddings or cfg.head_dim % 8:
+                raise ValueError("the 4-D position model has q/k norms and an untied 16-wide head")
+            # constant input vector [1,0,1,0,...] (/root/reference/src/model/modeling.py:389-394)
+            self.model.register_buffer("embed_vector", (1 - torch.arange(d, device=dev) % 2).float())
+            self._rope4d_f = None
+        elif cfg.tie_word_embeddings:
             _register(self, "lm_head.weight", self.model.embed_tokens.weight)
         # layer views
         self._layers = []
@@ -203,7 +212,8 @@ class MidiLM(GenerationMixin, nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         own = dict(self.named_parameters())
-        own_names = set(own) | ({"lm_head.weight"} if self.cfg.tie_word_embeddings else set())
+        own_names = set(own) | ({"lm_head.weight"} if self.cfg.tie_word_embeddings else set()) | \
+            ({"model.embed_vector"} if self.cfg.pos4d else set())
         missing = [k for k in own if k not in state_dict]
         unexpected = [k for k in state_dict if k not in own_names]
         if strict and (missing or unexpected):
@@ -231,13 +241,28 @@ class MidiLM(GenerationMixin, nn.Module):
             self._rope_npos = npos
         return self._rope_cs
 
+    def _rope4d_table(self, rows):
+        """cos/sin of the 4-axis angles of every note row ([T,4] fp32); the frequency vector is built with the
+        reference's expression (/root/reference/src/model/modeling.py:521-525) on the host so that it is
+        bit-identical."""
+        cfg = self.cfg
+        if self._rope4d_f is None:
+            Dh = cfg.head_dim
+            rot = Dh // 8 - cfg.rope4d_nope
+            f = 1.0 / (cfg.rope4d_theta ** (torch.arange(0, rot * 2, 2).float() / Dh))
+            self._rope4d_f = torch.cat([f, torch.zeros(cfg.rope4d_nope)]).to(self.flat_param.device)
+        return ops.rope4d_table(rows, self._rope4d_f, cfg.head_dim)
+
     # ------------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------------
-    def forward(self, input_ids=None, attention_mask=None, labels=None, num_logits_to_keep: int = 0, **unused):
+    def forward(self, input_ids=None, attention_mask=None, labels=None, num_logits_to_keep: int = 0,
+                position_tensors=None, **unused):
         """attention_mask is accepted for call compatibility. With right padding (what the reference's collators
         produce) causal attention already keeps real tokens from seeing pads, so loss and gradients do not depend
         on it; logits at pad positions are unspecified."""
+        if self.cfg.pos4d:
+            return self._forward_pos4d(position_tensors, labels)
         if input_ids is None:
             raise ValueError("You must specify input_ids")
         if input_ids.dim() != 2:
@@ -263,6 +288,67 @@ class MidiLM(GenerationMixin, nn.Module):
             logits = self._logits(hN).view(B, -1, self.cfg.vocab_size)
             return CausalLMOutput(loss=None, logits=logits)
 
+    def _forward_pos4d(self, position_tensors, labels):
+        """Call surface of the reference's 4-D model (/root/reference/src/model/model.py:296-303 ->
+        src/model/modeling.py:567-668): `position_tensors` float [B,S,4] note rows, `labels` float [B,S,4] (a row with
+        a -100 in it is ignored); returns `.loss` and `.logits` = the unit angle pairs [B,S,8,2] in fp32."""
+        if position_tensors is None or position_tensors.dim() != 3 or position_tensors.shape[-1] != 4:
+            raise ValueError("position_tensors must be [batch, seq, 4]")
+        if not position_tensors.is_cuda:
+            raise RuntimeError("MidiLM runs on the GPU only: position_tensors must be a CUDA/HIP tensor")
+        pt = position_tensors.contiguous().to(torch.float32)
+        B, S = pt.shape[:2]
+        if labels is not None:
+            if tuple(labels.shape) != (B, S, 4):
+                raise ValueError("labels must be [batch, seq, 4]")
+            labels = labels.contiguous().to(torch.float32)
+        self.sync_shadow()
+        if labels is not None and torch.is_grad_enabled():
+            loss = _LMTrainFunction.apply(self, pt, labels, self.lm_head.weight)
+        else:
+            with torch.no_grad():
+                xN, _ = self._run_layers(pt, save=None)
+                loss, _ = self._cos_head_loss(xN, labels, with_grad=False)
+        return CausalLMOutput(loss=loss, logits=self._last_pred.view(B, S, 8, 2))
+
+    def _cos_head_loss(self, xN, labels, with_grad: bool):
+        """16-wide head, unit-normalised pairs (kept in self._last_pred, fp32 [T,16]) and the cosine loss. With
+        with_grad, also returns d(loss)/d(xN) (bf16) and leaves d(loss)/d(W_head) in self._lm_grad_tmp, both for
+        upstream grad 1."""
+        cfg = self.cfg
+        T, d = xN.shape[0], cfg.hidden_size
+        dev = xN.device
+        W = self._view(self.flat_shadow, "lm_head.weight")
+        pairs = torch.empty(T, POS4D_HEAD_OUT, dtype=torch.bfloat16, device=dev)
+        ops.gemm(xN, W, pairs, T, POS4D_HEAD_OUT, d, xN.stride(0), W.stride(0), POS4D_HEAD_OUT)
+        pred = torch.empty(T, POS4D_HEAD_OUT, dtype=torch.float32, device=dev)
+        self._last_pred = pred
+        if labels is None:
+            ops.cos4d_fwd_bwd(pairs, None, None, 1.0, pred, None, None)
+            return None, None
+        inv_count = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.cos4d_count(labels, inv_count)
+        row_loss = torch.empty(T, dtype=torch.float32, device=dev)
+        dpairs = torch.empty(T, POS4D_HEAD_OUT, dtype=torch.bfloat16, device=dev) if with_grad else None
+        ops.cos4d_fwd_bwd(pairs, labels, inv_count, 1.0, pred, row_loss, dpairs)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        ops.ce_finalize(row_loss, inv_count, loss)
+        dxN = None
+        if with_grad:
+            dxN = torch.empty(T, d, dtype=torch.bfloat16, device=dev)
+            ops.gemm(dpairs, W, dxN, T, d, POS4D_HEAD_OUT, POS4D_HEAD_OUT, W.stride(0), d, False, True, ops.OUT_BF16)
+            if self._lm_grad_tmp is None:
+                self._lm_grad_tmp = torch.empty(POS4D_HEAD_OUT, d, dtype=torch.float32, device=dev)
+            self._lm_grad_tmp.zero_()   # accumulate mode lets the [16, d] output use the split-K path over T
+            ops.gemm(dpairs, xN, self._lm_grad_tmp, POS4D_HEAD_OUT, d, T, POS4D_HEAD_OUT, xN.stride(0), d, True, True,
+                     ops.OUT_F32_ACC)
+        return loss, dxN
+
+    def _head_loss(self, xN, labels, with_grad: bool):
+        if self.cfg.pos4d:
+            return self._cos_head_loss(xN, labels, with_grad)
+        return self._lm_head_loss(xN, labels, with_grad)
+
     def _logits(self, hN):
         cfg = self.cfg
         V = cfg.vocab_size
@@ -273,39 +359,55 @@ class MidiLM(GenerationMixin, nn.Module):
         ops.gemm(hN, W, buf, T, V, cfg.hidden_size, hN.stride(0), W.stride(0), ld)
         return buf[:, :V]
 
-    def _run_layers(self, input_ids, save: Optional[list], pos: Optional[torch.Tensor] = None, cache=None):
+    def _run_layers(self, inp, save: Optional[list], pos: Optional[torch.Tensor] = None, cache=None):
+        """inp: token ids int64 [B,S], or note rows fp32 [B,S,4] for the 4-D position model."""
         cfg = self.cfg
-        B, S = input_ids.shape
+        B, S = inp.shape[:2]
         T = B * S
         d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
                             cfg.intermediate_size)
-        dev = input_ids.device
+        dev = inp.device
         bf = torch.bfloat16
         NQ = cfg.qkv_width
         QK = (H + KVH) * Dh
-        cs = self._rope_table(S)
         scale = Dh ** -0.5
-        E = self.model.embed_tokens.weight
         h = torch.empty(T, d, dtype=torch.float32, device=dev)
-        ops.embedding_fwd(input_ids, E, h, self._err_flag)
+        if cfg.pos4d:
+            cs = self._rope4d_table(inp.view(T, 4))
+            ops.fill_rows(self.model.embed_vector, h)
+        else:
+            cs = self._rope_table(S)
+            ops.embedding_fwd(inp, self.model.embed_tokens.weight, h, self._err_flag)
         for l, v in enumerate(self._layers):
             x1 = torch.empty(T, d, dtype=bf, device=dev)
             rstd1 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h, v.w_ln1, x1, rstd1, cfg.rms_norm_eps)
             qkv = torch.empty(T, NQ, dtype=bf, device=dev)
             ops.linear_fwd(x1, v.s_qkv, qkv)
-            qk = torch.empty(T, QK, dtype=bf, device=dev)
-            ops.qknorm_rope_fwd(qkv, NQ, qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, S,
-                                T, H, KVH, Dh, cfg.rms_norm_eps)
+            if cfg.pos4d:
+                # q, k (normalised) and v all rotated: one [T, NQ] buffer in the layout of qkv
+                qk = torch.empty(T, NQ, dtype=bf, device=dev)
+                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qk.data_ptr() + 2 * QK
+                sq = sk = sv = NQ
+                ops.qkvnorm_rope4d_fwd(qkv.data_ptr(), NQ, qp, kp, vp, NQ, NQ, NQ, v.w_qn, v.w_kn, cs, T, H, KVH, KVH,
+                                       Dh, cfg.rms_norm_eps)
+            else:
+                qk = torch.empty(T, QK, dtype=bf, device=dev)
+                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK
+                sq, sk, sv = QK, QK, NQ
+                ops.qknorm_rope_fwd(qkv, NQ, qp, kp, QK, QK, v.w_qn, v.w_kn, cs, pos, S, T, H, KVH, Dh,
+                                    cfg.rms_norm_eps)
             if cache is not None:  # prefill: rotated keys and values of every prompt position go into the cache
-                ops.kv_append(qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK, QK, NQ, cache.k[l], cache.v[l],
-                              cache.zero_pos, B, S, KVH, Dh, cache.max_len)
+                ops.kv_append(kp, vp, sk, sv, cache.k[l], cache.v[l], cache.zero_pos, B, S, KVH, Dh, cache.max_len)
             att = torch.empty(T, H * Dh, dtype=bf, device=dev)
             lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-            ops.attn_fwd(qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK, att.data_ptr(), lse,
-                         QK, QK, NQ, H * Dh, B, S, H, KVH, Dh, scale)
+            ops.attn_fwd(qp, kp, vp, att.data_ptr(), lse, sq, sk, sv, H * Dh, B, S, H, KVH, Dh, scale)
+            att_o = att
+            if cfg.pos4d:  # the attention output is rotated back by each query's own angles before o_proj
+                att_o = torch.empty(T, H * Dh, dtype=bf, device=dev)
+                ops.rotate4d(att, att_o, cs, T, H, Dh, inverse=True)
             h_mid = torch.empty(T, d, dtype=torch.float32, device=dev)
-            ops.linear_fwd(att, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
+            ops.linear_fwd(att_o, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
             x2 = torch.empty(T, d, dtype=bf, device=dev)
             rstd2 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h_mid, v.w_ln2, x2, rstd2, cfg.rms_norm_eps)
@@ -316,12 +418,12 @@ class MidiLM(GenerationMixin, nn.Module):
             h_out = torch.empty(T, d, dtype=torch.float32, device=dev)
             ops.linear_fwd(act, v.s_down, h_out, ops.OUT_F32_RESID_BF16ROUND, h_mid)
             if save is not None:
-                save.append((h, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act))
+                save.append((h, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o))
             h = h_out
         xN = torch.empty(T, d, dtype=bf, device=dev)
         rstdN = torch.empty(T, dtype=torch.float32, device=dev)
         ops.rmsnorm_fwd(h, self.model.norm.weight, xN, rstdN, cfg.rms_norm_eps)
-        return xN, (h, rstdN)
+        return xN, (h, rstdN, cs)
 
     def _lm_head_loss(self, xN, labels, with_grad: bool):
         """Fused lm_head + shifted cross entropy over chunks of tokens. With with_grad, also returns
@@ -361,19 +463,18 @@ class MidiLM(GenerationMixin, nn.Module):
     # ------------------------------------------------------------------------------------------------
     # backward through the layer stack; gradients are ACCUMULATED into flat_grad
     # ------------------------------------------------------------------------------------------------
-    def _backward_layers(self, input_ids, saved, final, dxN, grad_hook=None):
+    def _backward_layers(self, inp, saved, final, dxN, grad_hook=None):
         cfg = self.cfg
-        B, S = input_ids.shape
+        B, S = inp.shape[:2]
         T = B * S
         d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
                             cfg.intermediate_size)
-        dev = input_ids.device
+        dev = inp.device
         bf = torch.bfloat16
         NQ = cfg.qkv_width
         QK = (H + KVH) * Dh
-        cs = self._rope_table(S)
         scale = Dh ** -0.5
-        h_last, rstdN = final
+        h_last, rstdN, cs = final
         dh = torch.empty(T, d, dtype=torch.float32, device=dev)
         dh_lp = torch.empty(T, d, dtype=bf, device=dev)
         g_norm = self._view(self.flat_grad, "model.norm.weight")
@@ -388,7 +489,7 @@ class MidiLM(GenerationMixin, nn.Module):
         delta = torch.empty(B, H, S, dtype=torch.float32, device=dev)
         for l in range(cfg.num_hidden_layers - 1, -1, -1):
             v = self._layers[l]
-            h_in, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act = saved[l]
+            h_in, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o = saved[l]
             # ---- MLP branch
             ops.linear_dgrad(dh_lp, v.s_down, dact)
             ops.linear_wgrad(dh_lp, act, v.g_down)
@@ -398,22 +499,34 @@ class MidiLM(GenerationMixin, nn.Module):
             ops.rmsnorm_bwd(dx, h_mid, v.w_ln2, rstd2, dh, dh_lp, v.g_ln2, accumulate=True)
             # ---- attention branch
             ops.linear_dgrad(dh_lp, v.s_o, datt)
-            ops.linear_wgrad(dh_lp, att, v.g_o)
-            qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK
+            ops.linear_wgrad(dh_lp, att_o, v.g_o)
             dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + 2 * H * Dh, dqkv.data_ptr() + 2 * QK
+            if cfg.pos4d:
+                # datt is the gradient of the rotated-back output: rotate it forward to reach the attention output
+                ops.rotate4d(datt, datt, cs, T, H, Dh, inverse=False)
+                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qk.data_ptr() + 2 * QK
+                sq = sk = sv = NQ
+            else:
+                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK
+                sq, sk, sv = QK, QK, NQ
             ops.attn_bwd(qp, kp, vp, att.data_ptr(), datt.data_ptr(), lse, delta, dqp, dkp, dvp,
-                         QK, QK, NQ, H * Dh, H * Dh, NQ, NQ, NQ, B, S, H, KVH, Dh, scale)
-            ops.qknorm_rope_bwd(dqp, NQ, dqp, dkp, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn, cs, None, S, T, H,
-                                KVH, Dh, cfg.rms_norm_eps)
+                         sq, sk, sv, H * Dh, H * Dh, NQ, NQ, NQ, B, S, H, KVH, Dh, scale)
+            if cfg.pos4d:
+                ops.qkvnorm_rope4d_bwd(dqp, NQ, dqp, dkp, dvp, NQ, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn,
+                                       cs, T, H, KVH, KVH, Dh, cfg.rms_norm_eps)
+            else:
+                ops.qknorm_rope_bwd(dqp, NQ, dqp, dkp, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn, cs, None, S,
+                                    T, H, KVH, Dh, cfg.rms_norm_eps)
             ops.linear_dgrad(dqkv, v.s_qkv, dx)
             ops.linear_wgrad(dqkv, x1, v.g_qkv)
             ops.rmsnorm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, accumulate=True)
             saved[l] = None
             if grad_hook is not None:
                 grad_hook(l)
-        ops.embedding_bwd(input_ids, dh, self._view(self.flat_grad, "model.embed_tokens.weight"))
-        if grad_hook is not None:
-            grad_hook("embed")
+        if not cfg.pos4d:  # the 4-D model's input is a constant: nothing to train below layer 0
+            ops.embedding_bwd(inp, dh, self._view(self.flat_grad, "model.embed_tokens.weight"))
+            if grad_hook is not None:
+                grad_hook("embed")
 
     # layout helpers for the data-parallel reducer -------------------------------------------------------
     def grad_ranges(self):
@@ -428,8 +541,9 @@ class MidiLM(GenerationMixin, nn.Module):
             end = o[f"model.layers.{l + 1}.input_layernorm.weight"] if l + 1 < cfg.num_hidden_layers else \
                 o["model.norm.weight"]
             out.append((l, start, end))
-        out.append(("embed", 0, o["model.layers.0.input_layernorm.weight"] if cfg.num_hidden_layers else
-                    o["model.norm.weight"]))
+        if not cfg.pos4d:
+            out.append(("embed", 0, o["model.layers.0.input_layernorm.weight"] if cfg.num_hidden_layers else
+                        o["model.norm.weight"]))
         return out
 
 
@@ -440,7 +554,7 @@ class _LMTrainFunction(torch.autograd.Function):
     def forward(ctx, model: MidiLM, input_ids, labels, _anchor):
         saved: list = []
         xN, final = model._run_layers(input_ids, save=saved)
-        loss, dxN = model._lm_head_loss(xN, labels, with_grad=True)
+        loss, dxN = model._head_loss(xN, labels, with_grad=True)
         ctx.model, ctx.input_ids, ctx.saved, ctx.final, ctx.dxN = model, input_ids, saved, final, dxN
         return loss
 

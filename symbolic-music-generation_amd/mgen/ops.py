@@ -84,6 +84,63 @@ def qknorm_rope_bwd(dqk, ld_in, dq_raw, dk_raw, ld_q, ld_k, raw, ld_raw, wq, wk,
          _p(dwk), _p(cs), _p(pos), S, T, HQ, HK, D, eps, int(is_bf16), _stream())
 
 
+def rope4d_table(pos4, freqs, D):
+    """pos4 [T,4] fp32 -> cos/sin table [T, D/2, 2] fp32."""
+    _need_gpu(pos4, freqs)
+    T = pos4.shape[0]
+    cs = torch.empty(T, D // 2, 2, dtype=torch.float32, device=pos4.device)
+    call("mgen_rope4d_table", _p(pos4), _p(freqs), _p(cs), T, D, _stream())
+    return cs
+
+
+def qkvnorm_rope4d_fwd(qkv, ld_in, qout, kout, vout, ld_q, ld_k, ld_v, wq, wk, cs, T, HQ, HK, HV, D, eps,
+                       is_bf16=True):
+    """qkv/qout/kout/vout are raw device pointers (ints)."""
+    call("mgen_qkvnorm_rope4d_fwd", qkv, ld_in, qout, kout, vout, ld_q, ld_k, ld_v, _p(wq), _p(wk), _p(cs), T, HQ, HK,
+         HV, D, eps, int(is_bf16), _stream())
+
+
+def qkvnorm_rope4d_bwd(dqkv, ld_in, dq, dk, dv, ld_q, ld_k, ld_v, raw, ld_raw, wq, wk, dwq, dwk, cs, T, HQ, HK, HV, D,
+                       eps, is_bf16=True):
+    call("mgen_qkvnorm_rope4d_bwd", dqkv, ld_in, dq, dk, dv, ld_q, ld_k, ld_v, _p(raw), ld_raw, _p(wq), _p(wk),
+         _p(dwq), _p(dwk), _p(cs), T, HQ, HK, HV, D, eps, int(is_bf16), _stream())
+
+
+def rotate4d(x, y, cs, T, H, D, inverse):
+    """y[T, H*D] = x rotated pairwise by +angle (inverse=False) or -angle (inverse=True); may be in place."""
+    _need_gpu(x, y, cs)
+    ld_x, ld_y = x.stride(0), y.stride(0)
+    if inverse:
+        call("mgen_qkvnorm_rope4d_bwd", x.data_ptr(), ld_x, 0, 0, y.data_ptr(), 0, 0, ld_y, 0, 0, 0, 0, 0, 0, _p(cs),
+             T, 0, 0, H, D, 0.0, int(x.dtype == torch.bfloat16), _stream())
+    else:
+        call("mgen_qkvnorm_rope4d_fwd", x.data_ptr(), ld_x, 0, 0, y.data_ptr(), 0, 0, ld_y, 0, 0, _p(cs), T, 0, 0, H, D,
+             0.0, int(x.dtype == torch.bfloat16), _stream())
+
+
+def fill_rows(vec, out):
+    _need_gpu(vec, out)
+    T, d = out.shape
+    call("mgen_fill_rows", _p(vec), _p(out), T, d, _stream())
+
+
+def cos4d_count(labels, inv_count, count=None):
+    _need_gpu(labels, inv_count)
+    call("mgen_cos4d_count", _p(labels), labels.numel() // 4, _p(inv_count), _p(count), _stream())
+
+
+def cos4d_fwd_bwd(pairs, labels, inv_count, grad_scale, pred_out, row_loss, dpairs):
+    _need_gpu(pairs)
+    T = pairs.shape[0]
+    call("mgen_cos4d_fwd_bwd", _p(pairs), _p(labels), _p(inv_count), grad_scale, _p(pred_out), _p(row_loss),
+         _p(dpairs), T, int(pairs.dtype == torch.bfloat16), _stream())
+
+
+def pos4d_next(pred, ld_pred, prev, ld_prev, nxt, ld_next, B):
+    """pred/prev/nxt are raw device pointers (ints) to fp32 rows."""
+    call("mgen_pos4d_next", pred, ld_pred, prev, ld_prev, nxt, ld_next, B, _stream())
+
+
 def attn_fwd(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, D, scale):
     """q/k/v/out are raw device pointers (ints) of token-major views; strides in elements."""
     call("mgen_attn_fwd", q, k, v, out, _p(lse), sq, sk, sv, so, B, S, H, KVH, D, scale, _stream())
