@@ -1,6 +1,5 @@
 // Next-token selection from one row of logits per stream: greedy argmax, or temperature -> top-k -> top-p -> one
-// multinomial draw, without sorting the vocabulary. One 1024-thread workgroup per row; every pass streams the row
-// (L2 / Infinity-Cache resident after the first) and ends in a wavefront + LDS reduction.
+// multinomial draw, without sorting the vocabulary.
 //
 // Reference: GenerationMixin._sample (transformers generation/utils.py:2894-2925) with the warpers
 // TemperatureLogitsWarper (generation/logits_process.py:301-303: scores / T), TopKLogitsWarper (:590-595: mask
@@ -9,10 +8,13 @@
 // argmax_i(probs_i / q_i) with q_i ~ Exp(1). The draw is made here from EXPLICIT noise: either a caller-supplied
 // q[B][V], or q = -ln(u) from a counter-based Philox4x32-10 stream that mgen_philox_exponential can also write out.
 //
-// Thresholds instead of a sort: floats are mapped to order-preserving 32-bit keys; the k-th largest key is found by
+// Thresholds instead of a sort: scores are mapped to order-preserving integer keys; the k-th largest key is found by
 // a 4-ary search on counts, and the top-p cut by a 4-ary search on the probability mass at or below a key (the
 // ascending cumulative sum of the reference, evaluated at a key). Elements with equal scores are kept or dropped
 // together (the reference's unstable sort leaves that case unspecified).
+//
+// Two kernels: a register-resident one for bf16 rows of up to 155 648 entries (the row is read from HBM once), and
+// a generic one (fp32 logits, longer or unaligned rows) that streams the row from cache in every pass.
 #include "common.h"
 
 namespace {
@@ -34,9 +36,10 @@ __device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsi
     const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
-// Exp(1) sample for element i of row `row` at stream position `offset`
-__device__ __forceinline__ float philox_exp(unsigned long long seed, unsigned long long offset, unsigned row, int i) {
-    unsigned c[4] = {(unsigned)(i >> 2), row, (unsigned)offset, (unsigned)(offset >> 32)};
+// the 4 words of block `blk` (= elements 4*blk .. 4*blk+3) of row `row` at stream position `offset`
+__device__ __forceinline__ void philox4(unsigned long long seed, unsigned long long offset, unsigned row, unsigned blk,
+                                        unsigned (&c)[4]) {
+    c[0] = blk; c[1] = row; c[2] = (unsigned)offset; c[3] = (unsigned)(offset >> 32);
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
@@ -44,17 +47,25 @@ __device__ __forceinline__ float philox_exp(unsigned long long seed, unsigned lo
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    const unsigned w = c[i & 3];
+}
+__device__ __forceinline__ float word_to_exp(unsigned w) {
     const float u = ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);  // 24-bit uniform in (0, 1)
-    return -logf(u);
+    return -0.6931471805599453f * __builtin_amdgcn_logf(u);           // hardware log2 (u is a normal number)
+}
+// Exp(1) sample for element i of row `row` at stream position `offset`
+__device__ __forceinline__ float philox_exp(unsigned long long seed, unsigned long long offset, unsigned row, int i) {
+    unsigned c[4];
+    philox4(seed, offset, row, (unsigned)(i >> 2), c);
+    return word_to_exp(c[i & 3]);
 }
 
-// ---- block reductions over 1024 threads ------------------------------------------------------------------
+// ---- block reductions over NW wavefronts --------------------------------------------------------------------
 struct Red {
     float f[16][3];
     unsigned long long u[16];
 };
 
+template <int NW = 16>
 __device__ __forceinline__ void block_sum3(float (&v)[3], Red& r) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -66,11 +77,12 @@ __device__ __forceinline__ void block_sum3(float (&v)[3], Red& r) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float s = 0.f;
-        for (int i = 0; i < 16; ++i) s += r.f[i][k];
+        for (int i = 0; i < NW; ++i) s += r.f[i][k];
         v[k] = s;
     }
 }
 // max over packed 64-bit (key << 32 | payload) values
+template <int NW = 16>
 __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v, Red& r) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -82,7 +94,7 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v
     if (lane == 0) r.u[w] = v;
     __syncthreads();
     unsigned long long m = r.u[0];
-    for (int i = 1; i < 16; ++i) m = r.u[i] > m ? r.u[i] : m;
+    for (int i = 1; i < NW; ++i) m = r.u[i] > m ? r.u[i] : m;
     return m;
 }
 
@@ -94,6 +106,7 @@ struct SampleArgs {
     long* out2; long out2_stride;  // optional second destination: out2[row * out2_stride]
 };
 
+// ---- generic kernel: one 1024-thread workgroup per row, every pass streams the row from cache ----------------
 template <typename LT>
 __global__ __launch_bounds__(NT) void sample_kernel(SampleArgs a) {
     __shared__ Red red;
@@ -217,6 +230,214 @@ __global__ __launch_bounds__(NT) void sample_kernel(SampleArgs a) {
     }
 }
 
+// ---- register-resident kernel for bf16 rows -------------------------------------------------------------------
+// A bf16 row of up to NCH*4096 logits (155 648 >= the 151 936-entry vocabulary) is read from HBM once, 16 bytes per
+// lane per chunk, converted to 16-bit order-preserving keys with packed 16-bit arithmetic, and stays in 152 VGPRs
+// per thread (512 threads: 2 wavefronts per SIMD, 256 VGPRs each); every later pass works on registers. bf16 has
+// only 2^16 distinct values and the order of logit / T equals the order of the logit for T > 0, so thresholds are
+// searched over those keys. Counts are taken wave-wide on the scalar unit (ballot + popcount). Each mass pass
+// evaluates exp() only for elements inside the interval that is still open (the mass below it is carried as a
+// running base), so after the first pass nearly all wavefronts skip the transcendental. Padding (beyond V) has
+// key 0, below the key of every number, and is never counted, summed or drawn.
+constexpr int FNT = 512;
+constexpr int NCH = 38;
+constexpr int FAST_MAX_V = NCH * FNT * 8;
+
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+
+__device__ __forceinline__ unsigned keys_of_pair(unsigned raw) {
+    const u16x2 b = __builtin_bit_cast(u16x2, raw);
+    const s16x2 sgn = __builtin_bit_cast(s16x2, raw) >> (short)15;                 // 0xFFFF for negatives
+    const u16x2 flip = __builtin_bit_cast(u16x2, sgn) | (unsigned short)0x8000;    // negatives: ~b, others: b | 0x8000
+    return __builtin_bit_cast(unsigned, (u16x2)(b ^ flip));
+}
+// the bf16 value behind a key, as a float
+__device__ __forceinline__ float key_val(unsigned k) {
+    const unsigned b = (k & 0x8000u) ? (k & 0x7FFFu) : (~k & 0xFFFFu);
+    return __uint_as_float(b << 16);
+}
+
+// (every pass xors the packed keys with a zero the compiler cannot see through: without it the 304 extracted keys
+// are hoisted out of the search loops as loop invariants and spill)
+// CHUNK_END runs after the 8 keys of a chunk: accumulating passes pin their partial sums there with an empty asm so
+// that the compiler does not re-associate a 304-term sum into a tree (which keeps every term alive and spills).
+#define MGEN_FOR_EACH_KEY2(BODY, CHUNK_END)                                            \
+    unsigned opaque_zero;                                                              \
+    asm volatile("s_mov_b32 %0, 0" : "=s"(opaque_zero));                               \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                  \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                \
+            const unsigned dw = pk[c][e >> 1] ^ opaque_zero;                           \
+            const unsigned k = (e & 1) ? (dw >> 16) : (dw & 0xFFFFu);                  \
+            BODY                                                                       \
+        }                                                                              \
+        CHUNK_END                                                                      \
+    }
+#define MGEN_FOR_EACH_KEY(BODY) MGEN_FOR_EACH_KEY2(BODY, {})
+
+__global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
+    constexpr int NW = FNT / 64;
+    __shared__ Red red;
+    const int row_i = blockIdx.x, tid = threadIdx.x, V = a.V;
+    const unsigned short* row = reinterpret_cast<const unsigned short*>(a.logits) + (long)row_i * a.ld;
+
+    u32x4 pk[NCH];
+    unsigned kmax = 0, kmin1 = 0xFFFFu;              // kmin1 = min over (key - 1) of the real entries
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int i0 = (c * FNT + tid) * 8;
+        u32x4 kk = {0u, 0u, 0u, 0u};
+        if (i0 < V) {                                 // ld is a multiple of 8 and >= V: the 16 bytes are readable
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(row + i0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kk[j] = keys_of_pair(raw[j]);
+            if (i0 + 8 > V) {                         // the one lane that straddles V
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (i0 + e >= V) kk[e >> 1] &= (e & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned klo = kk[j] & 0xFFFFu, khi = kk[j] >> 16;
+            kmax = max(kmax, max(klo, khi));
+            kmin1 = min(kmin1, min(klo - 1u, khi - 1u));   // padding (key 0) wraps to 0xFFFFFFFF
+        }
+        pk[c] = kk;
+    }
+
+    if (!a.do_sample) {
+        unsigned long long best = 0;
+        MGEN_FOR_EACH_KEY({
+            const int i = (c * FNT + tid) * 8 + e;
+            const unsigned long long p = ((unsigned long long)k << 32) | (unsigned)(~i);
+            best = p > best ? p : best;
+        })
+        best = block_max_u64<NW>(best, red);
+        if (tid == 0) {
+            const long tok = (long)(~(unsigned)best);
+            a.out[row_i] = tok;
+            if (a.out2) a.out2[(long)row_i * a.out2_stride] = tok;
+        }
+        return;
+    }
+
+    kmax =(unsigned)(block_max_u64<NW>((unsigned long long)kmax << 32, red) >> 32);
+    const unsigned kmin = 0x10000u - (unsigned)(block_max_u64<NW>((unsigned long long)(0xFFFFu - kmin1) << 32, red) >> 32);
+    const float T = a.temperature;
+    // score = logit / T, correctly rounded, from a refined reciprocal and one residual step (3 FMAs per element)
+    const bool unit_T = T == 1.0f;
+    float rT = __builtin_amdgcn_rcpf(T);
+    rT = fmaf(fmaf(-T, rT, 1.0f), rT, rT);
+    auto score = [&](unsigned k) -> float {
+        const float l = key_val(k);
+        if (unit_T) return l;
+        const float q0 = l * rT;
+        const float q1 = fmaf(fmaf(-T, q0, l), rT, q0);
+        return (k == 0x007Fu) ? l : q1;              // -inf stays -inf (the residual would be inf - inf)
+    };
+    const float smax = score(kmax);
+
+    // ---- top-k: the largest key x with count{key >= x} >= k
+    unsigned kcut = kmin;
+    if (a.top_k > 0 && a.top_k < V) {
+        unsigned lo = kmin, hi = kmax;       // answer in [lo, hi]; base = count{key > hi}
+        float base = 0.f;
+        const float kf = (float)a.top_k;
+        while (lo < hi) {
+            const unsigned span = hi - lo;   // thresholds in (lo, hi]
+            const unsigned m1 = lo + (span + 3) / 4, m2 = lo + (span + 1) / 2, m3 = hi - span / 4;
+            // k in [m, hi]  <=>  (k - m) <= (hi - m) as unsigned: one subtract + one compare + one add-with-carry
+            int n1 = 0, n2 = 0, n3 = 0;
+            const unsigned w1 = hi - m1, w2 = hi - m2, w3 = hi - m3;
+            MGEN_FOR_EACH_KEY2({
+                n1 += (k - m1) <= w1 ? 1 : 0;
+                n2 += (k - m2) <= w2 ? 1 : 0;
+                n3 += (k - m3) <= w3 ? 1 : 0;
+            }, { asm volatile("" : "+v"(n1), "+v"(n2), "+v"(n3)); })
+            float cnt[3] = {(float)n1, (float)n2, (float)n3};
+            block_sum3<NW>(cnt, red);        // counts < 2^24 are exact in fp32
+            if (base + cnt[2] >= kf) lo = m3;
+            else if (base + cnt[1] >= kf) { lo = m2; hi = m3 - 1; base += cnt[2]; }
+            else if (base + cnt[0] >= kf) { lo = m1; hi = m2 - 1; base += cnt[1]; }
+            else { hi = m1 - 1; base += cnt[0]; }
+        }
+        kcut = lo;
+    }
+
+    // ---- normaliser of the top-k survivors and top-p: the smallest key x with mass{kcut <= key <= x} > (1-p) Z
+    const float c2 = LOG2E;
+    unsigned lo = kcut, hi = kmax;           // answer in [lo, hi]; below = mass{kcut <= key < lo}
+    float below = 0.f, Z = 0.f, thr = 0.f;
+    bool first = true;
+    const bool want_p = a.top_p < 1.0f;
+    while (first || (want_p && lo < hi)) {
+        const unsigned span = hi - lo;       // thresholds in [lo, hi); the first pass also measures Z at kmax
+        const unsigned m1 = lo + span / 4, m2 = lo + span / 2, m3 = first ? kmax : lo + span / 2 + span / 4;
+        float f[3] = {0.f, 0.f, 0.f};
+        MGEN_FOR_EACH_KEY({
+            const bool in = k >= lo && k <= m3;
+            if (__builtin_amdgcn_ballot_w64(in) != 0ull) {
+                const float ee = in ? __builtin_amdgcn_exp2f((score(k) - smax) * c2) : 0.f;
+                f[2] += ee;
+                f[1] += k <= m2 ? ee : 0.f;
+                f[0] += k <= m1 ? ee : 0.f;
+            }
+        })
+        block_sum3<NW>(f, red);
+        if (first) {
+            Z = f[2];
+            thr = (1.0f - a.top_p) * Z;
+            first = false;
+            if (!want_p) break;
+            if (f[0] > thr) hi = m1;
+            else if (f[1] > thr) { lo = m1 + 1; hi = m2; below += f[0]; }
+            else { lo = m2 + 1; below += f[1]; }
+            continue;
+        }
+        if (below + f[0] > thr) hi = m1;
+        else if (below + f[1] > thr) { lo = m1 + 1; hi = m2; below += f[0]; }
+        else if (below + f[2] > thr) { lo = m2 + 1; hi = m3; below += f[1]; }
+        else { lo = m3 + 1; below += f[2]; }
+    }
+    if (want_p) kcut = lo;
+    const float Zk = Z - below;              // mass of the final survivors
+
+    // ---- the draw: argmax over the survivors of (e_i / Zk) / q_i; one Philox block serves 4 neighbouring elements
+    unsigned long long best = 0;
+#pragma unroll 2
+    for (int c = 0; c < NCH; ++c) {
+        const u32x4 kk = pk[c];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned k4[4] = {kk[2 * h] & 0xFFFFu, kk[2 * h] >> 16, kk[2 * h + 1] & 0xFFFFu, kk[2 * h + 1] >> 16};
+            const bool any4 = k4[0] >= kcut || k4[1] >= kcut || k4[2] >= kcut || k4[3] >= kcut;
+            if (__builtin_amdgcn_ballot_w64(any4) == 0ull) continue;
+            if (any4) {
+                const int i4 = (c * FNT + tid) * 8 + 4 * h;
+                unsigned w[4];
+                if (!a.noise) philox4(a.seed, a.offset, row_i, (unsigned)(i4 >> 2), w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (k4[e] >= kcut) {
+                        const float q = a.noise ? a.noise[(long)row_i * a.ld_noise + i4 + e] : word_to_exp(w[e]);
+                        const float sc = (__builtin_amdgcn_exp2f((score(k4[e]) - smax) * c2) / Zk) / q;
+                        const unsigned long long p =
+                            ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(~(i4 + e));
+                        best = p > best ? p : best;
+                    }
+                }
+            }
+        }
+    }
+    best = block_max_u64<NW>(best, red);
+    if (tid == 0) {
+        const long tok = (long)(~(unsigned)best);
+        a.out[row_i] = tok;
+        if (a.out2) a.out2[(long)row_i * a.out2_stride] = tok;
+    }
+}
+
 __global__ void philox_exp_kernel(float* __restrict__ out, long ld, int B, int V, unsigned long long seed,
                                   unsigned long long offset) {
     const long n = (long)B * V;
@@ -245,7 +466,9 @@ extern "C" int mgen_sample(const void* logits, long ld, int B, int V, int is_bf1
     a.logits = logits; a.ld = ld; a.V = V; a.temperature = temperature; a.top_k = top_k; a.top_p = top_p;
     a.do_sample = do_sample; a.noise = noise; a.ld_noise = ld_noise; a.seed = seed; a.offset = offset; a.out = out;
     a.out2 = out2; a.out2_stride = out2_stride;
-    if (is_bf16) hipLaunchKernelGGL((sample_kernel<bf16>), dim3(B), dim3(NT), 0, stream, a);
+    const bool fast = is_bf16 && V <= FAST_MAX_V && ld % 8 == 0 && ((uintptr_t)logits % 16) == 0;
+    if (fast) hipLaunchKernelGGL(sample_bf16_kernel, dim3(B), dim3(FNT), 0, stream, a);
+    else if (is_bf16) hipLaunchKernelGGL((sample_kernel<bf16>), dim3(B), dim3(NT), 0, stream, a);
     else hipLaunchKernelGGL((sample_kernel<float>), dim3(B), dim3(NT), 0, stream, a);
     return mgen_check_launch("mgen_sample");
 }

@@ -1,0 +1,32 @@
+"""Time the next-token selection kernel on [B, V] bf16 logits (GPU box only)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
+from mgen import ops  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+V = int(sys.argv[2]) if len(sys.argv) > 2 else 151936
+ld = (V + 7) // 8 * 8
+g = torch.Generator(device="cuda").manual_seed(0)
+logits = (torch.randn(B, ld, device="cuda", generator=g) * 3.0).bfloat16()
+out = torch.empty(B, dtype=torch.int64, device="cuda")
+for name, kw in (("greedy", dict(do_sample=False, temperature=1.0, top_k=0, top_p=1.0)),
+                 ("T0.97 p0.95", dict(do_sample=True, temperature=0.97, top_k=0, top_p=0.95)),
+                 ("T0.97 k50 p0.95", dict(do_sample=True, temperature=0.97, top_k=50, top_p=0.95)),
+                 ("T1 k5", dict(do_sample=True, temperature=1.0, top_k=5, top_p=1.0)),
+                 ("T1 plain", dict(do_sample=True, temperature=1.0, top_k=0, top_p=1.0))):
+    for _ in range(3):
+        ops.sample(logits, V, out, kw["do_sample"], kw["temperature"], kw["top_k"], kw["top_p"], None, 1234, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 20
+    for i in range(n):
+        ops.sample(logits, V, out, kw["do_sample"], kw["temperature"], kw["top_k"], kw["top_p"], None, 1234, i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"{name:18s} {dt * 1e6:8.1f} us   ({B * V * 2 / dt / 1e9:7.1f} GB/s of logits)")
