@@ -123,6 +123,32 @@ int mgen_embedding_fwd(const long* ids, const float* table, float* out, long T, 
                        mgen_stream_t stream);
 int mgen_embedding_bwd(const long* ids, const float* dout, float* dtable, long T, int d, long V, mgen_stream_t stream);
 
+/* ---- GPT-2 style decoder (reference src/model/model.py:54-65 builds transformers' GPT2LMHeadModel) ---------------
+ * Conv1D layers = torch.addmm(bias, x, W) with W stored [in][out] (TF pytorch_utils.py Conv1D.forward): the product
+ * of mgen_gemm_bf16 with transB=1 plus a bf16 bias row [N] added to the fp32 accumulators before the output rounding
+ * (alpha = 1; out_mode 0, 1, 3 or 4). */
+int mgen_gemm_bf16_bias(const void* A, const void* B, void* C, const void* resid, const void* bias, int M, int N,
+                        int K, long lda, long ldb, long ldc, long ldr, int transA, int transB, int out_mode,
+                        mgen_stream_t stream);
+/* nn.LayerNorm over the fp32 residual stream (TF models/gpt2/modeling_gpt2.py ln_1/ln_2/ln_f, eps 1e-5):
+ * y = (x - mean) * rstd * w + b; mean[T], rstd[T] saved for backward (may be null). */
+int mgen_layernorm_fwd(const float* x, const float* w, const float* b, void* y, float* mean, float* rstd, long T,
+                       int d, float eps, int out_bf16, mgen_stream_t stream);
+/* dres (+)= d(loss)/dx (fp32), dres_lp = the same in the dtype of dy (may be null), dw[d] += , db[d] += . */
+int mgen_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                       float* dres, void* dres_lp, float* dw, float* db, long T, int d, int accumulate, int dy_bf16,
+                       mgen_stream_t stream);
+/* NewGELUActivation (TF activations.py: 0.5 x (1 + tanh(sqrt(2/pi)(x + 0.044715 x^3)))) on bf16 [n], n % 8 == 0,
+ * evaluated in fp32; backward dh = dact * gelu'(h). */
+int mgen_gelu_new_fwd(const void* h, void* act, long n, mgen_stream_t stream);
+int mgen_gelu_new_bwd(const void* h, const void* dact, void* dh, long n, mgen_stream_t stream);
+/* out[n] += sum_t x[t][n] for bf16 x [T][ld]: the bias gradient of a Conv1D from its output gradient. */
+int mgen_colsum_bf16(const void* x, long ld, float* out, long T, int N, mgen_stream_t stream);
+/* wte[ids[t]] + wpe[pos[t]] (GPT2Model.forward: inputs_embeds + position_embeds); pos int32 [T] or null
+ * (position = t % S); *err_flag is set when an id or position is out of range. */
+int mgen_embed_pos_fwd(const long* ids, const float* wte, const float* wpe, const int* pos, float* out, long T, int S,
+                       int d, long V, int P, int* err_flag, mgen_stream_t stream);
+
 /* dtype conversion: kind 0 fp32 -> bf16, 1 bf16 -> fp32. */
 int mgen_cast(const void* in, void* out, long n, int kind, mgen_stream_t stream);
 

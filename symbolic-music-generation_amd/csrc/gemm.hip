@@ -26,6 +26,7 @@ struct GemmArgs {
     const bf16* B;
     void* C;
     const float* R;  // residual for the OUT_F32_RESID* modes
+    const bf16* bias;  // optional [N] added to the accumulator before any rounding (torch.addmm under autocast)
     int M, N, K;
     long lda, ldb, ldc, ldr;
     float alpha;
@@ -217,6 +218,23 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
         return;
     }
     const int h = lane >> 5;
+    if (g.bias) {
+        // the lane holds, per tile, columns 8*g4 + 4*h + e of the tile: add the bias to the fp32 accumulators
+        // (alpha is 1 whenever a bias is given)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + wn + 32 * j + 8 * g4 + 4 * h;
+                float b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = (n + e < g.N) ? (float)g.bias[n + e] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g4 + e] += b[e];
+            }
+    }
     if (MODE == OUT_BF16 && (g.ldc & 7) == 0) {
         // bf16 output through LDS: the wave parks its 64x64 sub-tile in its own 8 KiB of the (now idle) staging
         // area as [64 rows][128 bytes] with the 16-byte chunks XOR-swizzled by row, then writes whole 128-byte row
@@ -367,10 +385,13 @@ int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void* resid, int M, int N, int K,
-                              long lda, long ldb, long ldc, long ldr, int transA, int transB, int out_mode,
-                              float alpha, hipStream_t stream) {
+static int gemm_impl(const void* A, const void* B, void* C, const void* resid, const void* bias, int M, int N, int K,
+                     long lda, long ldb, long ldc, long ldr, int transA, int transB, int out_mode, float alpha,
+                     hipStream_t stream) {
     MGEN_REQUIRE(A && B && C, "mgen_gemm_bf16: null operand");
+    if (bias)
+        MGEN_REQUIRE(alpha == 1.0f && out_mode != OUT_F32_ACC,
+                     "mgen_gemm_bf16_bias: a bias goes with alpha = 1 and a non-accumulating output");
     MGEN_REQUIRE(M > 0 && N > 0 && K > 0, "mgen_gemm_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     MGEN_REQUIRE((lda % 8) == 0 && (ldb % 8) == 0, "mgen_gemm_bf16: lda/ldb must be multiples of 8 elements");
     MGEN_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
@@ -387,7 +408,7 @@ extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void*
     if (out_mode == OUT_F32_RESID_BF16ROUND || out_mode == OUT_F32_RESID)
         MGEN_REQUIRE(resid != nullptr && ldr >= N, "mgen_gemm_bf16: residual mode needs resid and ldr>=N");
     GemmArgs g;
-    g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.R = (const float*)resid;
+    g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.R = (const float*)resid; g.bias = (const bf16*)bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.nbm = (M + BM - 1) / BM; g.nbn = (N + BN - 1) / BN;
     MGEN_REQUIRE(out_mode >= 0 && out_mode <= OUT_F32_RESID, "mgen_gemm_bf16: unknown out_mode %d", out_mode);
@@ -417,4 +438,19 @@ extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void*
     if (transA && !transB) MGEN_GEMM_GO(true, false);
     MGEN_GEMM_GO(true, true);
 #undef MGEN_GEMM_GO
+}
+
+extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void* resid, int M, int N, int K,
+                              long lda, long ldb, long ldc, long ldr, int transA, int transB, int out_mode,
+                              float alpha, hipStream_t stream) {
+    return gemm_impl(A, B, C, resid, nullptr, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_mode, alpha, stream);
+}
+
+// Same product with a bias row (bf16 [N]) added to the fp32 accumulators before the output rounding: the fused
+// torch.addmm(bias, x, W) of GPT-2's Conv1D layers (transformers pytorch_utils.py Conv1D.forward) under autocast.
+extern "C" int mgen_gemm_bf16_bias(const void* A, const void* B, void* C, const void* resid, const void* bias, int M,
+                                   int N, int K, long lda, long ldb, long ldc, long ldr, int transA, int transB,
+                                   int out_mode, hipStream_t stream) {
+    MGEN_REQUIRE(bias != nullptr, "mgen_gemm_bf16_bias: null bias");
+    return gemm_impl(A, B, C, resid, bias, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_mode, 1.0f, stream);
 }

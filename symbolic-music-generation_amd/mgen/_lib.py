@@ -31,6 +31,13 @@ SIGNATURES = {
     "mgen_swiglu_bwd": [P, P, P, L, I, P],
     "mgen_embedding_fwd": [P, P, P, L, I, L, P, P],
     "mgen_embedding_bwd": [P, P, P, L, I, L, P],
+    "mgen_gemm_bf16_bias": [P, P, P, P, P, I, I, I, L, L, L, L, I, I, I, P],
+    "mgen_layernorm_fwd": [P, P, P, P, P, P, L, I, F, I, P],
+    "mgen_layernorm_bwd": [P, P, P, P, P, P, P, P, P, L, I, I, I, P],
+    "mgen_gelu_new_fwd": [P, P, L, P],
+    "mgen_gelu_new_bwd": [P, P, P, L, P],
+    "mgen_colsum_bf16": [P, L, P, L, I, P],
+    "mgen_embed_pos_fwd": [P, P, P, P, P, L, I, I, L, I, P, P],
     "mgen_cast": [P, P, L, I, P],
     "mgen_ce_count": [P, L, I, L, P, P, P],
     "mgen_ce_fwd_bwd": [P, P, L, L, I, L, I, L, P, F, P, P, I, I, P],

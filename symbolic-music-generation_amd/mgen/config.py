@@ -31,6 +31,10 @@ class LMConfig:
     # velocity] rows through an adjacent-pair rotary embedding of q, k AND v; no token embedding; a 16-wide head
     # predicting 8 unit angle pairs trained with a cosine loss
     pos4d: bool = False
+    # "llama": RMSNorm + RoPE + SwiGLU blocks (Qwen3 / Llama); "gpt2": LayerNorm + learned positions + gelu_new blocks
+    # with biased Conv1D layers (mgen.gpt2.MidiGPT2LM)
+    arch: str = "llama"
+    layer_norm_eps: float = 1e-5
     rope4d_theta: float = 10000.0     # fixed in the reference (:510), independent of rope_theta
     rope4d_nope: int = 4              # zero frequencies ("NoPE" pairs) at the end of each axis' block (:522-525)
 
@@ -51,6 +55,14 @@ def pos4d_decoder() -> LMConfig:
     """The reference's 4-D position model (MidiQwenNew, src/model/model.py:273-290): the default decoder's shape
     without a vocabulary."""
     return LMConfig(vocab_size=1, tie_word_embeddings=False, pos4d=True)
+
+
+def gpt2_decoder(vocab_size: int = 30000, n_positions: int = 4096) -> LMConfig:
+    """The reference's GPT-2 variant (MidiGPT2, src/model/model.py:54-64): n_embd 512, 6 layers, 8 heads; the
+    vocabulary is the trained tokenizer's (30 000), n_positions = CONTEXT_SIZE = 4096 (src/utils.py:4)."""
+    return LMConfig(arch="gpt2", vocab_size=vocab_size, hidden_size=512, intermediate_size=2048, num_hidden_layers=6,
+                    num_attention_heads=8, num_key_value_heads=8, head_dim=64, max_position_embeddings=n_positions,
+                    tie_word_embeddings=True, qk_norm=False)
 
 
 def aria_style_llama() -> LMConfig:

@@ -107,7 +107,7 @@ class MidiLM(GenerationMixin, nn.Module):
         self.device_ = torch.device(device)
         d = cfg.hidden_size
         assert cfg.head_dim in (64, 128) and d % 8 == 0 and cfg.intermediate_size % 8 == 0
-        layout = param_layout(cfg)
+        layout = self._param_layout()
         offs, off = {}, 0
         for name, shape in layout:
             # q/k/v and gate/up must stay back to back: their sizes are multiples of _ALIGN already
@@ -124,14 +124,7 @@ class MidiLM(GenerationMixin, nn.Module):
             prm = nn.Parameter(self._view(self.flat_param, name), requires_grad=True)
             prm.grad = self._view(self.flat_grad, name)
             _register(self, name, prm)
-        if cfg.pos4d:
-            if not cfg.qk_norm or cfg.tie_word_embeddings or cfg.head_dim % 8:
-                raise ValueError("the 4-D position model has q/k norms and an untied 16-wide head")
-            # constant input vector [1,0,1,0,...] (/root/reference/src/model/modeling.py:389-394)
-            self.model.register_buffer("embed_vector", (1 - torch.arange(d, device=dev) % 2).float())
-            self._rope4d_f = None
-        elif cfg.tie_word_embeddings:
-            _register(self, "lm_head.weight", self.model.embed_tokens.weight)
+        self._post_register(dev)
         # layer views
         self._layers = []
         for l in range(cfg.num_hidden_layers):
@@ -146,6 +139,25 @@ class MidiLM(GenerationMixin, nn.Module):
     # ------------------------------------------------------------------------------------------------
     # parameter store
     # ------------------------------------------------------------------------------------------------
+    def _param_layout(self):
+        return param_layout(self.cfg)
+
+    def _post_register(self, dev):
+        """Buffers and tied names that go with the parameters."""
+        cfg = self.cfg
+        if cfg.pos4d:
+            if not cfg.qk_norm or cfg.tie_word_embeddings or cfg.head_dim % 8:
+                raise ValueError("the 4-D position model has q/k norms and an untied 16-wide head")
+            # constant input vector [1,0,1,0,...] (/root/reference/src/model/modeling.py:389-394)
+            self.model.register_buffer("embed_vector", (1 - torch.arange(cfg.hidden_size, device=dev) % 2).float())
+            self._rope4d_f = None
+        elif cfg.tie_word_embeddings:
+            _register(self, "lm_head.weight", self.model.embed_tokens.weight)
+
+    def _anchor(self):
+        """A parameter handed to the autograd node so that it has a differentiable input."""
+        return self.lm_head.weight
+
     def _view(self, flat, name, shape=None, count=None):
         shape = shape or self._shapes[name]
         n = count or _numel(shape)
@@ -274,7 +286,7 @@ class MidiLM(GenerationMixin, nn.Module):
             labels = labels.contiguous().to(torch.int64)
         self.sync_shadow()
         if labels is not None and torch.is_grad_enabled():
-            loss = _LMTrainFunction.apply(self, input_ids, labels, self.model.embed_tokens.weight)
+            loss = _LMTrainFunction.apply(self, input_ids, labels, self._anchor())
             return CausalLMOutput(loss=loss, logits=None)
         with torch.no_grad():
             hN, _ = self._run_layers(input_ids, save=None)

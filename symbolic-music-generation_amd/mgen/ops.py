@@ -55,6 +55,66 @@ def linear_wgrad(dy, x, dw, accumulate=True, n_rows=None, n_cols=None):
          OUT_F32_ACC if accumulate else OUT_F32)
 
 
+def gemm_bias(a, b, c, bias, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode=OUT_BF16, resid=None,
+              ldr=0):
+    """gemm() with a bf16 bias row [N] added to the accumulators before the output rounding."""
+    _need_gpu(a, b, c, bias)
+    call("mgen_gemm_bf16_bias", _p(a), _p(b), _p(c), _p(resid), _p(bias), M, N, K, lda, ldb, ldc, ldr, int(trans_a),
+         int(trans_b), out_mode, _stream())
+
+
+def conv1d_fwd(x, w, bias, out, out_mode=OUT_BF16, resid=None):
+    """out[T,N] = x[T,K] @ w[K,N] + bias[N]  (GPT-2 Conv1D: weight stored [in, out])."""
+    T, K = x.shape
+    N = w.shape[1]
+    gemm_bias(x, w, out, bias, T, N, K, x.stride(0), w.stride(0), out.stride(0), False, True, out_mode, resid,
+              resid.stride(0) if resid is not None else 0)
+
+
+def conv1d_dgrad(dy, w, dx):
+    """dx[T,K] = dy[T,N] @ w[K,N]^T."""
+    T, N = dy.shape
+    K = w.shape[0]
+    gemm(dy, w, dx, T, K, N, dy.stride(0), w.stride(0), dx.stride(0), False, False, OUT_BF16)
+
+
+def conv1d_wgrad(dy, x, dw, db):
+    """dw[K,N] += x[T,K]^T @ dy[T,N];  db[N] += column sums of dy."""
+    T, N = dy.shape
+    K = x.shape[1]
+    gemm(x, dy, dw, K, N, T, x.stride(0), dy.stride(0), dw.stride(0), True, True, OUT_F32_ACC)
+    call("mgen_colsum_bf16", _p(dy), dy.stride(0), _p(db), T, N, _stream())
+
+
+def layernorm_fwd(x, w, b, y, mean, rstd, eps):
+    T, d = x.shape
+    call("mgen_layernorm_fwd", _p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), T, d, eps,
+         int(y.dtype == torch.bfloat16), _stream())
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dres, dres_lp, dw, db, accumulate):
+    T, d = x.shape
+    call("mgen_layernorm_bwd", _p(dy), _p(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dres_lp), _p(dw), _p(db), T, d,
+         int(accumulate), int(dy.dtype == torch.bfloat16), _stream())
+
+
+def gelu_new_fwd(h, act):
+    _need_gpu(h, act)
+    call("mgen_gelu_new_fwd", _p(h), _p(act), h.numel(), _stream())
+
+
+def gelu_new_bwd(h, dact, dh):
+    _need_gpu(h, dact, dh)
+    call("mgen_gelu_new_bwd", _p(h), _p(dact), _p(dh), h.numel(), _stream())
+
+
+def embed_pos_fwd(ids, wte, wpe, pos, out, S, err_flag=None):
+    _need_gpu(ids, wte, wpe, out)
+    T, d = out.shape
+    call("mgen_embed_pos_fwd", _p(ids), _p(wte), _p(wpe), _p(pos), _p(out), T, S, d, wte.shape[0], wpe.shape[0],
+         _p(err_flag), _stream())
+
+
 def rmsnorm_fwd(x, w, y, rstd, eps):
     T, d = x.shape
     call("mgen_rmsnorm_fwd", _p(x), _p(w), _p(y), _p(rstd), T, d, eps, int(y.dtype == torch.bfloat16), _stream())

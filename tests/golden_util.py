@@ -44,6 +44,21 @@ def tiny_params_pos4d(cfg=TINY_POS4D):
     return params
 
 
+TINY_GPT2 = R.LMConfig(vocab_size=1000, hidden_size=256, intermediate_size=1024, num_hidden_layers=2,
+                       num_attention_heads=4, num_key_value_heads=4, head_dim=64, max_position_embeddings=1024,
+                       tie_word_embeddings=True, qk_norm=False)
+
+
+def tiny_params_gpt2(cfg=TINY_GPT2):
+    from oracle import ref_gpt2 as G
+    params = G.init_params_gpt2(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    for k in params:
+        if ".ln_" in k or k.endswith(".bias"):
+            params[k] = params[k] + 0.1 * torch.randn(params[k].shape, generator=g)
+    return params
+
+
 def checksum(params):
     return float(sum(v.double().abs().sum() for v in params.values()))
 

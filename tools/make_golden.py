@@ -391,10 +391,110 @@ def pos4d_case(name="tiny_pos4d", B=2, S=128):
     print(name, "fp32 loss", out["fp32_loss"], "bf16 loss", out["bf16_loss"], "last loss", losses[-1])
 
 
+GPT2_GRAD_KEYS = ["transformer.wte.weight", "transformer.wpe.weight", "transformer.h.0.ln_1.weight",
+                  "transformer.h.0.ln_1.bias", "transformer.h.0.attn.c_attn.weight", "transformer.h.0.attn.c_attn.bias",
+                  "transformer.h.0.attn.c_proj.weight", "transformer.h.0.attn.c_proj.bias",
+                  "transformer.h.0.mlp.c_fc.weight", "transformer.h.0.mlp.c_fc.bias",
+                  "transformer.h.1.mlp.c_proj.weight", "transformer.h.1.mlp.c_proj.bias", "transformer.ln_f.weight",
+                  "transformer.ln_f.bias"]
+
+
+def gpt2_case(name="tiny_gpt2", B=2, S=128):
+    """transformers' GPT2LMHeadModel (what /root/reference/src/model/model.py:54-65 builds) with dropout off."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from oracle import ref_gpt2 as G
+    cfg = R.LMConfig(vocab_size=1000, hidden_size=256, intermediate_size=1024, num_hidden_layers=2,
+                     num_attention_heads=4, num_key_value_heads=4, head_dim=64, max_position_embeddings=1024,
+                     tie_word_embeddings=True, qk_norm=False)
+    params = G.init_params_gpt2(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    for k in params:   # non-trivial gains and biases
+        if ".ln_" in k or k.endswith(".bias"):
+            params[k] = params[k] + 0.1 * torch.randn(params[k].shape, generator=g)
+
+    def build():
+        hc = GPT2Config(vocab_size=cfg.vocab_size, n_positions=cfg.max_position_embeddings, n_embd=cfg.hidden_size,
+                        n_layer=cfg.num_hidden_layers, n_head=cfg.num_attention_heads, resid_pdrop=0.0,
+                        embd_pdrop=0.0, attn_pdrop=0.0, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+        m = GPT2LMHeadModel(hc)
+        missing, unexpected = m.load_state_dict(params, strict=False)
+        assert not unexpected and all(k == "lm_head.weight" for k in missing), (missing, unexpected)
+        m.tie_weights()
+        return m.train()
+
+    m = build()
+    gen = torch.Generator().manual_seed(1234)
+    ids = torch.randint(3, cfg.vocab_size, (B, S), generator=gen)
+    out = {"param_checksum": checksum(params), "input_ids": ids.numpy()}
+    m.zero_grad()
+    o = m(input_ids=ids, labels=ids)
+    o.loss.backward()
+    out["fp32_loss"] = o.loss.item()
+    out["fp32_logits"] = o.logits.detach().numpy()
+    gr = grads_of(m)
+    for k in GPT2_GRAD_KEYS:
+        out["fp32_grad/" + k] = gr[k].numpy()
+    out["fp32_grad_norm"] = torch.linalg.vector_norm(
+        torch.stack([torch.linalg.vector_norm(g_) for g_ in gr.values()])).item()
+
+    # padded batch
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, S - 37:] = 0
+    lab = ids.clone()
+    lab[mask == 0] = -100
+    m.zero_grad()
+    o = m(input_ids=ids, attention_mask=mask, labels=lab)
+    o.loss.backward()
+    out["pad_mask"], out["pad_labels"], out["pad_loss"] = mask.numpy(), lab.numpy(), o.loss.item()
+    out["pad_grad/" + GPT2_GRAD_KEYS[4]] = grads_of(m)[GPT2_GRAD_KEYS[4]].numpy()
+
+    # bf16 autocast
+    m.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        o = m(input_ids=ids, labels=ids)
+    o.loss.backward()
+    out["bf16_loss"] = o.loss.item()
+    out["bf16_logits"] = o.logits.detach().float().numpy()
+
+    # 14 optimizer steps, lr 3e-4 (MidiGPT2 default), clip 1.0
+    opt = torch.optim.AdamW(m.parameters(), lr=3e-4, weight_decay=0.1, betas=(0.9, 0.95), eps=1e-5)
+    warm = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1e-6, end_factor=1.0, total_iters=10)
+    dec = torch.optim.lr_scheduler.LinearLR(opt, start_factor=1.0, end_factor=0.1, total_iters=12 * 20 - 10)
+    sch = torch.optim.lr_scheduler.SequentialLR(opt, [warm, dec], milestones=[10])
+    lrs, losses = [], []
+    for step in range(14):
+        m.zero_grad()
+        o = m(input_ids=ids, labels=ids)
+        o.loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+        losses.append(o.loss.item())
+    out["train_lrs"], out["train_losses"] = np.array(lrs), np.array(losses)
+
+    # greedy decode from the seeded weights
+    m = build().eval()
+    with torch.no_grad():
+        gtok = m.generate(ids[:1, :8], max_new_tokens=256, do_sample=False, eos_token_id=None, pad_token_id=0,
+                          use_cache=True)
+        lg = m(input_ids=gtok[:, :-1]).logits[0, 7:, :]
+    out["greedy_tokens"] = gtok.numpy()
+    top2 = torch.topk(lg, 2, dim=-1)[0]
+    out["greedy_margin"] = (top2[:, 0] - top2[:, 1]).numpy()
+    out = {k: slim(v) if isinstance(v, np.ndarray) and ("grad/" in k or "logits" in k) else v for k, v in out.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "fp32 loss", out["fp32_loss"], "bf16 loss", out["bf16_loss"], "pad loss", out["pad_loss"],
+          "last", losses[-1])
+
+
 if __name__ == "__main__":
     print("transformers", transformers.__version__, "torch", torch.__version__)
     if "--pos4d-only" in sys.argv:
         pos4d_case()
+        sys.exit(0)
+    if "--gpt2-only" in sys.argv:
+        gpt2_case()
         sys.exit(0)
     tiny_q = R.LMConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                         num_attention_heads=2, num_key_value_heads=2, head_dim=128)
