@@ -149,6 +149,23 @@ int mgen_colsum_bf16(const void* x, long ld, float* out, long T, int N, mgen_str
 int mgen_embed_pos_fwd(const long* ids, const float* wte, const float* wpe, const int* pos, float* out, long T, int S,
                        int d, long V, int P, int* err_flag, mgen_stream_t stream);
 
+/* ---- fp32 parity mode ------------------------------------------------------------------------------------------
+ * The network without autocast (reference src/train_aria.py:323-331 trains in fp32; the fp32 outputs of the stock
+ * modules are what the parity fixtures hold). Products run on the bf16 MFMA GEMM from split operands:
+ * hi = bf16(x), lo = bf16(x - hi), x*w ~= hi*hi + hi*lo + lo*hi with fp32 accumulation. n % 4 == 0. */
+int mgen_split_bf16(const float* x, void* hi, void* lo, long n, mgen_stream_t stream);
+/* Qwen3MLP gate in fp32 (TF models/qwen3/modeling_qwen3.py:81-83): gu [T][2I] = [gate | up]. */
+int mgen_swiglu_f32_fwd(const float* gu, float* act, long T, int I, mgen_stream_t stream);
+int mgen_swiglu_f32_bwd(const float* gu, const float* dact, float* dgu, long T, int I, mgen_stream_t stream);
+/* Causal attention in fp32 (eager formula, TF models/qwen3/modeling_qwen3.py:185-207) on token-major operands with
+ * the strides of mgen_attn_fwd/bwd (in elements); lse, delta [B][H][S]. */
+int mgen_attn_f32_fwd(const float* q, const float* k, const float* v, float* out, float* lse, long sq, long sk, long sv,
+                      long so, int B, int S, int H, int KVH, int D, float scale, mgen_stream_t stream);
+int mgen_attn_f32_bwd(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                      const float* lse, float* delta, float* dq, float* dk, float* dv, long sq, long sk, long sv, long so,
+                      long sdo, long sdq, long sdk, long sdv, int B, int S, int H, int KVH, int D, float scale,
+                      mgen_stream_t stream);
+
 /* dtype conversion: kind 0 fp32 -> bf16, 1 bf16 -> fp32. */
 int mgen_cast(const void* in, void* out, long n, int kind, mgen_stream_t stream);
 
@@ -174,7 +191,7 @@ int mgen_grad_norm_clip(const float* grad, long n, float max_norm, double* works
 int mgen_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,
                     const float* clip, float lr, float beta1, float beta2, float eps, float wd, long step,
                     mgen_stream_t stream);
-int mgen_scale_f32(float* x, long n, float s, mgen_stream_t stream);
+int mgen_scale_f32(float* x, long n, float s, const float* a_dev, mgen_stream_t stream);
 /* y += a * (*a_dev) * x ; x *= a * (*a_dev)  (a_dev may be null): the upstream loss gradient stays on the device. */
 int mgen_axpy_f32(float* y, const float* x, long n, float a, const float* a_dev, mgen_stream_t stream);
 int mgen_scale_bf16(void* x, long n, float a, const float* a_dev, mgen_stream_t stream);

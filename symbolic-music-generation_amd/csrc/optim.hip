@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
-__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float s) {
+__global__ __launch_bounds__(256) void scale_kernel(float* __restrict__ x, long n, float s,
+                                                    const float* __restrict__ a_dev) {
+    if (a_dev) s *= *a_dev;
     const long n4 = n / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
@@ -144,11 +146,12 @@ extern "C" int mgen_adamw_step(float* param, const float* grad, float* exp_avg, 
     return mgen_check_launch("mgen_adamw_step");
 }
 
-extern "C" int mgen_scale_f32(float* x, long n, float s, hipStream_t stream) {
+// x *= s * (*a_dev) over n fp32 elements (n % 4 == 0); a_dev may be null
+extern "C" int mgen_scale_f32(float* x, long n, float s, const float* a_dev, hipStream_t stream) {
     MGEN_REQUIRE(x && n > 0 && n % 4 == 0, "mgen_scale_f32: bad arguments");
     long nb = (n / 4 + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, n, s);
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)nb), dim3(256), 0, stream, x, n, s, a_dev);
     return mgen_check_launch("mgen_scale_f32");
 }
 

@@ -38,13 +38,18 @@ SIGNATURES = {
     "mgen_gelu_new_bwd": [P, P, P, L, P],
     "mgen_colsum_bf16": [P, L, P, L, I, P],
     "mgen_embed_pos_fwd": [P, P, P, P, P, L, I, I, L, I, P, P],
+    "mgen_split_bf16": [P, P, P, L, P],
+    "mgen_swiglu_f32_fwd": [P, P, L, I, P],
+    "mgen_swiglu_f32_bwd": [P, P, P, L, I, P],
+    "mgen_attn_f32_fwd": [P, P, P, P, P, L, L, L, L, I, I, I, I, I, F, P],
+    "mgen_attn_f32_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, P],
     "mgen_cast": [P, P, L, I, P],
     "mgen_ce_count": [P, L, I, L, P, P, P],
     "mgen_ce_fwd_bwd": [P, P, L, L, I, L, I, L, P, F, P, P, I, I, P],
     "mgen_ce_finalize": [P, L, P, P, P],
     "mgen_grad_norm_clip": [P, L, F, P, P, P],
     "mgen_adamw_step": [P, P, P, P, P, L, P, F, F, F, F, F, L, P],
-    "mgen_scale_f32": [P, L, F, P],
+    "mgen_scale_f32": [P, L, F, P, P],
     "mgen_axpy_f32": [P, P, L, F, P, P],
     "mgen_scale_bf16": [P, L, F, P, P],
     "mgen_kv_append": [P, P, L, L, P, P, P, I, I, I, I, I, P],

@@ -134,6 +134,35 @@ class GenerationMixin:
         self.sync_shadow()
         out = torch.empty(B, total, dtype=torch.int64, device=dev)
         out[:, :P] = input_ids
+        if not use_cache or getattr(self, "act_dtype", torch.bfloat16) == torch.float32:
+            # no cache (and the fp32 parity mode, whose cache-less arithmetic is the reference's own): every step
+            # runs the whole prefix through the training forward and keeps the last row of logits
+            nxt = torch.empty(B, dtype=torch.int64, device=dev)
+            unfinished = torch.ones(B, dtype=torch.int64, device=dev) if eos_token_id is not None else None
+            step_logits = [] if return_step_logits else None
+            n_done = 0
+            for step in range(max_new_tokens):
+                xN, _ = self._run_layers(out[:, :P + step].contiguous(), save=None)
+                last = xN.view(B, P + step, -1)[:, -1, :].contiguous()
+                logits = self._logits(last)
+                ld = logits.stride(0)
+                full = logits.as_strided((B, ld), (ld, 1))
+                nz = noise[step] if (noise is not None and do_sample) else None
+                ops.sample(full, V, nxt, do_sample, temperature, top_k or 0, top_p, nz, seed, step)
+                if return_step_logits:
+                    step_logits.append(logits.float().clone())
+                tok = nxt
+                if unfinished is not None:
+                    tok = nxt * unfinished + pad_token_id * (1 - unfinished)
+                    unfinished.mul_((tok != eos_token_id).long())
+                out[:, P + step] = tok
+                n_done = step + 1
+                if unfinished is not None and int(unfinished.max()) == 0:
+                    break
+            out = out[:, :P + n_done]
+            if self._err_flag is not None and int(self._err_flag) != 0:
+                raise IndexError("token id out of range in generate()")
+            return (out, torch.stack(step_logits, 0)) if return_step_logits else out
         cache = KVCache(cfg, B, total, dev)
         buf = _DecodeBuffers(cfg, B, dev)
         # lens[t] = int32 [B] filled with t: per-stream positions / key counts without per-step host->device traffic

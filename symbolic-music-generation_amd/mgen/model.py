@@ -100,8 +100,14 @@ class _LayerViews:
 class MidiLM(GenerationMixin, nn.Module):
     def __init__(self, cfg: LMConfig, device="cuda", seed: Optional[int] = 0, compute_dtype=torch.bfloat16):
         super().__init__()
-        if compute_dtype != torch.bfloat16:
-            raise NotImplementedError("only the bf16-mixed compute path (fp32 master weights) is built")
+        if compute_dtype not in (torch.bfloat16, torch.float32):
+            raise NotImplementedError("compute_dtype is torch.bfloat16 (bf16-mixed, the training path) or torch.float32 "
+                                      "(parity mode)")
+        if compute_dtype == torch.float32 and (cfg.pos4d or cfg.arch != "llama"):
+            raise NotImplementedError("the fp32 parity mode covers the token models with RMSNorm/RoPE/SwiGLU blocks")
+        # bf16: what precision="bf16-mixed" computes. fp32: no rounding anywhere; products run on the bf16 MFMA GEMM
+        # from operands split into hi + lo halves (three products per GEMM), attention and the gate in plain fp32
+        self.act_dtype = compute_dtype
         self.cfg = cfg
         self.config = cfg
         self.device_ = torch.device(device)
@@ -119,6 +125,8 @@ class MidiLM(GenerationMixin, nn.Module):
         self.flat_param = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        self.flat_shadow_lo = torch.zeros(off, dtype=torch.bfloat16, device=dev) \
+            if compute_dtype == torch.float32 else None
         self._shadow_version = -1
         for name, shape in layout:
             prm = nn.Parameter(self._view(self.flat_param, name), requires_grad=True)
@@ -169,20 +177,29 @@ class MidiLM(GenerationMixin, nn.Module):
         p = f"model.layers.{l}."
         d, I = cfg.hidden_size, cfg.intermediate_size
         v = _LayerViews()
-        for tag, flat in (("w", self.flat_param), ("g", self.flat_grad), ("s", self.flat_shadow)):
-            setattr(v, tag + "_ln1", self._view(flat, p + "input_layernorm.weight"))
-            setattr(v, tag + "_qkv", self._view(flat, p + "self_attn.q_proj.weight", (cfg.qkv_width, d)))
-            setattr(v, tag + "_o", self._view(flat, p + "self_attn.o_proj.weight"))
-            setattr(v, tag + "_ln2", self._view(flat, p + "post_attention_layernorm.weight"))
-            setattr(v, tag + "_gu", self._view(flat, p + "mlp.gate_proj.weight", (2 * I, d)))
-            setattr(v, tag + "_down", self._view(flat, p + "mlp.down_proj.weight"))
+        for tag, flat in (("w", self.flat_param), ("g", self.flat_grad), ("s", None)):
+            view = (lambda name, shape=None: self._w(name, shape)) if flat is None else \
+                (lambda name, shape=None, flat=flat: self._view(flat, name, shape))
+            setattr(v, tag + "_ln1", view(p + "input_layernorm.weight"))
+            setattr(v, tag + "_qkv", view(p + "self_attn.q_proj.weight", (cfg.qkv_width, d)))
+            setattr(v, tag + "_o", view(p + "self_attn.o_proj.weight"))
+            setattr(v, tag + "_ln2", view(p + "post_attention_layernorm.weight"))
+            setattr(v, tag + "_gu", view(p + "mlp.gate_proj.weight", (2 * I, d)))
+            setattr(v, tag + "_down", view(p + "mlp.down_proj.weight"))
             if cfg.qk_norm:
-                setattr(v, tag + "_qn", self._view(flat, p + "self_attn.q_norm.weight"))
-                setattr(v, tag + "_kn", self._view(flat, p + "self_attn.k_norm.weight"))
+                setattr(v, tag + "_qn", view(p + "self_attn.q_norm.weight"))
+                setattr(v, tag + "_kn", view(p + "self_attn.k_norm.weight"))
             else:
                 setattr(v, tag + "_qn", None)
                 setattr(v, tag + "_kn", None)
         return v
+
+    def _w(self, name, shape=None):
+        """The GEMM operand form of a weight: its bf16 shadow, or the (hi, lo) pair in the fp32 parity mode."""
+        hi = self._view(self.flat_shadow, name, shape)
+        if self.flat_shadow_lo is None:
+            return hi
+        return ops.W2(hi, self._view(self.flat_shadow_lo, name, shape))
 
     def init_weights(self, seed: int = 0):
         """HF `_init_weights`: N(0, 0.02) for linear and embedding weights, ones for the norm gains."""
@@ -202,11 +219,16 @@ class MidiLM(GenerationMixin, nn.Module):
         """Refresh the bf16 shadow from the fp32 master if the master changed through torch (the fused optimizer
         writes both itself and calls mark_shadow_fresh)."""
         if self._shadow_version != self.flat_param._version:
-            ops.cast(self.flat_param, self.flat_shadow)
+            if self.flat_shadow_lo is not None:
+                ops.split_bf16_into(self.flat_param, self.flat_shadow, self.flat_shadow_lo)
+            else:
+                ops.cast(self.flat_param, self.flat_shadow)
             self._shadow_version = self.flat_param._version
 
     def mark_shadow_fresh(self):
-        self._shadow_version = self.flat_param._version
+        """Called by the fused optimizer after it rewrote the master weights and the bf16 shadow in one kernel."""
+        # (that kernel refreshes only the hi half: the fp32 parity mode splits again at the next forward)
+        self._shadow_version = self.flat_param._version if self.flat_shadow_lo is None else -1
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
@@ -364,11 +386,11 @@ class MidiLM(GenerationMixin, nn.Module):
     def _logits(self, hN):
         cfg = self.cfg
         V = cfg.vocab_size
-        W = self._view(self.flat_shadow, self._lm_head_name())
+        W = self._w(self._lm_head_name())
         T = hN.shape[0]
         ld = (V + 7) // 8 * 8
-        buf = torch.empty(T, ld, dtype=torch.bfloat16, device=hN.device)
-        ops.gemm(hN, W, buf, T, V, cfg.hidden_size, hN.stride(0), W.stride(0), ld)
+        buf = torch.empty(T, ld, dtype=self.act_dtype, device=hN.device)
+        ops.gemm_any(hN, W, buf, T, V, cfg.hidden_size, hN.stride(0), W.stride(0), ld)
         return buf[:, :V]
 
     def _run_layers(self, inp, save: Optional[list], pos: Optional[torch.Tensor] = None, cache=None):
@@ -379,7 +401,9 @@ class MidiLM(GenerationMixin, nn.Module):
         d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
                             cfg.intermediate_size)
         dev = inp.device
-        bf = torch.bfloat16
+        bf = self.act_dtype                     # dtype of the activations the GEMMs read and write
+        f32 = bf == torch.float32
+        esz = 4 if f32 else 2                   # bytes per element, for the pointer offsets into qkv / qk
         NQ = cfg.qkv_width
         QK = (H + KVH) * Dh
         scale = Dh ** -0.5
@@ -405,7 +429,7 @@ class MidiLM(GenerationMixin, nn.Module):
                                        Dh, cfg.rms_norm_eps)
             else:
                 qk = torch.empty(T, QK, dtype=bf, device=dev)
-                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK
+                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qkv.data_ptr() + esz * QK
                 sq, sk, sv = QK, QK, NQ
                 ops.qknorm_rope_fwd(qkv, NQ, qp, kp, QK, QK, v.w_qn, v.w_kn, cs, pos, S, T, H, KVH, Dh,
                                     cfg.rms_norm_eps)
@@ -413,7 +437,7 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.kv_append(kp, vp, sk, sv, cache.k[l], cache.v[l], cache.zero_pos, B, S, KVH, Dh, cache.max_len)
             att = torch.empty(T, H * Dh, dtype=bf, device=dev)
             lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
-            ops.attn_fwd(qp, kp, vp, att.data_ptr(), lse, sq, sk, sv, H * Dh, B, S, H, KVH, Dh, scale)
+            ops.attn_fwd(qp, kp, vp, att.data_ptr(), lse, sq, sk, sv, H * Dh, B, S, H, KVH, Dh, scale, f32=f32)
             att_o = att
             if cfg.pos4d:  # the attention output is rotated back by each query's own angles before o_proj
                 att_o = torch.empty(T, H * Dh, dtype=bf, device=dev)
@@ -445,28 +469,29 @@ class MidiLM(GenerationMixin, nn.Module):
         T = B * S
         V, d = cfg.vocab_size, cfg.hidden_size
         dev = xN.device
-        W = self._view(self.flat_shadow, self._lm_head_name())
+        W = self._w(self._lm_head_name())
         ld = (V + 7) // 8 * 8
         chunk = min(cfg.lm_head_chunk_tokens, T)
         inv_count = torch.empty(1, dtype=torch.float32, device=dev)
         ops.ce_count(labels, inv_count)
         row_loss = torch.empty(T, dtype=torch.float32, device=dev)
-        logits = torch.empty(chunk, ld, dtype=torch.bfloat16, device=dev)
-        dxN = torch.empty(T, d, dtype=torch.bfloat16, device=dev) if with_grad else None
+        logits = torch.empty(chunk, ld, dtype=self.act_dtype, device=dev)
+        dxN = torch.empty(T, d, dtype=self.act_dtype, device=dev) if with_grad else None
         if with_grad:
             if self._lm_grad_tmp is None:
                 self._lm_grad_tmp = torch.empty(V, d, dtype=torch.float32, device=dev)
         first = True
         for t0 in range(0, T, chunk):
             n = min(chunk, T - t0)
-            xc = xN[t0:t0 + n]
-            ops.gemm(xc, W, logits, n, V, d, xc.stride(0), W.stride(0), ld)
+            xc = ops.presplit(xN[t0:t0 + n])
+            ops.gemm_any(xc, W, logits, n, V, d, xc.stride(0), W.stride(0), ld)
             ops.ce_fwd_bwd(logits, labels, t0, n, V, ld, S, inv_count, 1.0, row_loss, None, write_grad=with_grad)
             if with_grad:
                 # dxN[c] = dlogits[c] @ W ; dW += dlogits[c]^T @ xN[c]
-                ops.gemm(logits, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
-                ops.gemm(logits, xc, self._lm_grad_tmp, V, d, n, ld, xc.stride(0), d, True, True,
-                         ops.OUT_F32 if first else ops.OUT_F32_ACC)
+                dl = ops.presplit(logits)
+                ops.gemm_any(dl, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
+                ops.gemm_any(dl, xc, self._lm_grad_tmp, V, d, n, ld, xc.stride(0), d, True, True,
+                             ops.OUT_F32 if first else ops.OUT_F32_ACC)
                 first = False
         loss = torch.empty((), dtype=torch.float32, device=dev)
         ops.ce_finalize(row_loss, inv_count, loss)
@@ -482,7 +507,9 @@ class MidiLM(GenerationMixin, nn.Module):
         d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
                             cfg.intermediate_size)
         dev = inp.device
-        bf = torch.bfloat16
+        bf = self.act_dtype
+        f32 = bf == torch.float32
+        esz = 4 if f32 else 2
         NQ = cfg.qkv_width
         QK = (H + KVH) * Dh
         scale = Dh ** -0.5
@@ -512,23 +539,23 @@ class MidiLM(GenerationMixin, nn.Module):
             # ---- attention branch
             ops.linear_dgrad(dh_lp, v.s_o, datt)
             ops.linear_wgrad(dh_lp, att_o, v.g_o)
-            dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + 2 * H * Dh, dqkv.data_ptr() + 2 * QK
+            dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + esz * H * Dh, dqkv.data_ptr() + esz * QK
             if cfg.pos4d:
                 # datt is the gradient of the rotated-back output: rotate it forward to reach the attention output
                 ops.rotate4d(datt, datt, cs, T, H, Dh, inverse=False)
                 qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qk.data_ptr() + 2 * QK
                 sq = sk = sv = NQ
             else:
-                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qkv.data_ptr() + 2 * QK
+                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qkv.data_ptr() + esz * QK
                 sq, sk, sv = QK, QK, NQ
             ops.attn_bwd(qp, kp, vp, att.data_ptr(), datt.data_ptr(), lse, delta, dqp, dkp, dvp,
-                         sq, sk, sv, H * Dh, H * Dh, NQ, NQ, NQ, B, S, H, KVH, Dh, scale)
+                         sq, sk, sv, H * Dh, H * Dh, NQ, NQ, NQ, B, S, H, KVH, Dh, scale, f32=f32)
             if cfg.pos4d:
                 ops.qkvnorm_rope4d_bwd(dqp, NQ, dqp, dkp, dvp, NQ, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn,
                                        cs, T, H, KVH, KVH, Dh, cfg.rms_norm_eps)
             else:
                 ops.qknorm_rope_bwd(dqp, NQ, dqp, dkp, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn, cs, None, S,
-                                    T, H, KVH, Dh, cfg.rms_norm_eps)
+                                    T, H, KVH, Dh, cfg.rms_norm_eps, is_bf16=not f32)
             ops.linear_dgrad(dqkv, v.s_qkv, dx)
             ops.linear_wgrad(dqkv, x1, v.g_qkv)
             ops.rmsnorm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, accumulate=True)
@@ -578,7 +605,10 @@ class _LMTrainFunction(torch.autograd.Function):
         # the upstream gradient stays on the device: everything below is linear in it
         go = grad_out.to(torch.float32).contiguous()
         dxN = ctx.dxN
-        ops.scale_bf16_(dxN, 1.0, go)
+        if dxN.dtype == torch.float32:
+            ops.scale_(dxN, 1.0, go)
+        else:
+            ops.scale_bf16_(dxN, 1.0, go)
         name = model._lm_head_name()
         ops.axpy_(model._view(model.flat_grad, name).view(-1), model._lm_grad_tmp.view(-1), 1.0, go)
         model._backward_layers(ctx.input_ids, ctx.saved, ctx.final, dxN, getattr(model, "_grad_hook", None))

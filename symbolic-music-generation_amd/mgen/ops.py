@@ -31,19 +31,72 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode
          out_mode, alpha, _stream())
 
 
+class W2:
+    """A weight of the fp32 parity mode: hi = bf16(w), lo = bf16(w - hi), two bf16 tensors of w's shape."""
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+        self.shape = hi.shape
+
+    def stride(self, i):
+        return self.hi.stride(i)
+
+
+def split_bf16(x):
+    """fp32 tensor (contiguous memory) -> (hi, lo) bf16 tensors of the same shape and strides."""
+    _need_gpu(x)
+    hi = torch.empty_like(x, dtype=torch.bfloat16)
+    lo = torch.empty_like(x, dtype=torch.bfloat16)
+    call("mgen_split_bf16", _p(x), _p(hi), _p(lo), x.numel(), _stream())
+    return hi, lo
+
+
+def split_bf16_into(x, hi, lo):
+    _need_gpu(x, hi, lo)
+    call("mgen_split_bf16", _p(x), _p(hi), _p(lo), x.numel(), _stream())
+
+
+def presplit(t):
+    """An fp32 activation that feeds several products: split once. bf16 tensors pass through."""
+    return W2(*split_bf16(t)) if (isinstance(t, torch.Tensor) and t.dtype == torch.float32) else t
+
+
+def _parts(t):
+    if isinstance(t, W2):
+        return t.hi, t.lo
+    if t.dtype == torch.float32:
+        return split_bf16(t)
+    return t, None
+
+
+def gemm_any(a, b, c, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode=OUT_BF16, resid=None, ldr=0):
+    """gemm() whose operands may be fp32 tensors or W2 pairs: then the product is hi*hi + hi*lo + lo*hi accumulated
+    in fp32 into an fp32 `c` (bf16-store and bf16-round epilogues become their fp32 counterparts)."""
+    ah, al = _parts(a)
+    bh, bl = _parts(b)
+    if al is None and bl is None:
+        return gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, resid, ldr)
+    if al is None or bl is None:
+        raise RuntimeError("gemm_any: both operands must be bf16 or both fp32 / split")
+    mode = {OUT_BF16: OUT_F32, OUT_F32_RESID_BF16ROUND: OUT_F32_RESID}.get(out_mode, out_mode)
+    gemm(ah, bh, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, mode, resid, ldr)
+    gemm(ah, bl, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, OUT_F32_ACC)
+    gemm(al, bh, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, OUT_F32_ACC)
+
+
 def linear_fwd(x, w, out, out_mode=OUT_BF16, resid=None):
     """out[T,N] = x[T,K] @ w[N,K]^T for contiguous 2-D tensors."""
     T, K = x.shape
     N = w.shape[0]
-    gemm(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), False, False, out_mode, resid,
-         resid.stride(0) if resid is not None else 0)
+    gemm_any(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), False, False, out_mode, resid,
+             resid.stride(0) if resid is not None else 0)
 
 
 def linear_dgrad(dy, w, dx):
     """dx[T,K] = dy[T,N] @ w[N,K]."""
     T, N = dy.shape
     K = w.shape[1]
-    gemm(dy, w, dx, T, K, N, dy.stride(0), w.stride(0), dx.stride(0), False, True, OUT_BF16)
+    gemm_any(dy, w, dx, T, K, N, dy.stride(0), w.stride(0), dx.stride(0), False, True, OUT_BF16)
 
 
 def linear_wgrad(dy, x, dw, accumulate=True, n_rows=None, n_cols=None):
@@ -51,8 +104,8 @@ def linear_wgrad(dy, x, dw, accumulate=True, n_rows=None, n_cols=None):
     T = dy.shape[0]
     N = n_rows if n_rows is not None else dy.shape[1]
     K = n_cols if n_cols is not None else x.shape[1]
-    gemm(dy, x, dw, N, K, T, dy.stride(0), x.stride(0), dw.stride(0), True, True,
-         OUT_F32_ACC if accumulate else OUT_F32)
+    gemm_any(dy, x, dw, N, K, T, dy.stride(0), x.stride(0), dw.stride(0), True, True,
+             OUT_F32_ACC if accumulate else OUT_F32)
 
 
 def gemm_bias(a, b, c, bias, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode=OUT_BF16, resid=None,
@@ -201,24 +254,33 @@ def pos4d_next(pred, ld_pred, prev, ld_prev, nxt, ld_next, B):
     call("mgen_pos4d_next", pred, ld_pred, prev, ld_prev, nxt, ld_next, B, _stream())
 
 
-def attn_fwd(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, D, scale):
-    """q/k/v/out are raw device pointers (ints) of token-major views; strides in elements."""
-    call("mgen_attn_fwd", q, k, v, out, _p(lse), sq, sk, sv, so, B, S, H, KVH, D, scale, _stream())
+def attn_fwd(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, D, scale, f32=False):
+    """q/k/v/out are raw device pointers (ints) of token-major views (bf16, or fp32 with f32=True); strides in
+    elements."""
+    call("mgen_attn_f32_fwd" if f32 else "mgen_attn_fwd", q, k, v, out, _p(lse), sq, sk, sv, so, B, S, H, KVH, D,
+         scale, _stream())
 
 
-def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, sq, sk, sv, so, sdo, sdq, sdk, sdv, B, S, H, KVH, D, scale):
-    call("mgen_attn_bwd", q, k, v, out, dout, _p(lse), _p(delta), dq, dk, dv, sq, sk, sv, so, sdo, sdq, sdk, sdv, B,
-         S, H, KVH, D, scale, _stream())
+def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, sq, sk, sv, so, sdo, sdq, sdk, sdv, B, S, H, KVH, D, scale,
+             f32=False):
+    call("mgen_attn_f32_bwd" if f32 else "mgen_attn_bwd", q, k, v, out, dout, _p(lse), _p(delta), dq, dk, dv, sq, sk,
+         sv, so, sdo, sdq, sdk, sdv, B, S, H, KVH, D, scale, _stream())
 
 
 def swiglu_fwd(gu, act, round_silu=True):
     T, I = act.shape
-    call("mgen_swiglu_fwd", _p(gu), _p(act), T, I, int(round_silu), _stream())
+    if gu.dtype == torch.float32:
+        call("mgen_swiglu_f32_fwd", _p(gu), _p(act), T, I, _stream())
+    else:
+        call("mgen_swiglu_fwd", _p(gu), _p(act), T, I, int(round_silu), _stream())
 
 
 def swiglu_bwd(gu, dact, dgu):
     T, I = dact.shape
-    call("mgen_swiglu_bwd", _p(gu), _p(dact), _p(dgu), T, I, _stream())
+    if gu.dtype == torch.float32:
+        call("mgen_swiglu_f32_bwd", _p(gu), _p(dact), _p(dgu), T, I, _stream())
+    else:
+        call("mgen_swiglu_bwd", _p(gu), _p(dact), _p(dgu), T, I, _stream())
 
 
 def embedding_fwd(ids, table, out, err_flag=None):
@@ -262,8 +324,8 @@ def adamw_step(p, g, m, v, shadow, clip, lr, beta1, beta2, eps, wd, step):
          step, _stream())
 
 
-def scale_(x, s):
-    call("mgen_scale_f32", _p(x), x.numel(), s, _stream())
+def scale_(x, s=1.0, a_dev=None):
+    call("mgen_scale_f32", _p(x), x.numel(), s, _p(a_dev), _stream())
 
 
 def axpy_(y, x, a=1.0, a_dev=None):

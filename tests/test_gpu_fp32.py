@@ -1,0 +1,180 @@
+"""The fp32 parity mode of the token models on the GPU against the fp32 fixtures made from the stock transformers
+modules (tests/golden). Tolerance: 1e-4 relative (max-norm), the budget stated for fp32 loss and logits."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R
+from golden_util import CASES, load, tiny_params, slim, rel_err
+
+FP32_TOL = 1e-4
+
+
+def _cfg(ocfg, **kw):
+    from mgen.config import LMConfig
+    return LMConfig(**{k: getattr(ocfg, k) for k in R.LMConfig.__dataclass_fields__}, **kw)
+
+
+@pytest.mark.parametrize("T,N,K", [(300, 512, 256), (64, 1032, 520), (1000, 256, 2048)])
+def test_split_product_is_fp32_accurate(T, N, K):
+    from mgen import ops
+    g = torch.Generator().manual_seed(T + N)
+    x = torch.randn(T, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.05
+    ref = (x.double() @ w.double().t())
+    xd, wd = x.cuda(), w.cuda()
+    hi, lo = ops.split_bf16(wd)
+    assert torch.equal(hi, wd.bfloat16())
+    assert float((wd - hi.float() - lo.float()).abs().max()) < 2e-5 * float(wd.abs().max())
+    out = torch.empty(T, N, device="cuda")
+    ops.linear_fwd(xd, ops.W2(hi, lo), out)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-5
+    resid = torch.randn(T, N, generator=g)
+    ops.linear_fwd(xd, ops.W2(hi, lo), out, ops.OUT_F32_RESID_BF16ROUND, resid.cuda())   # becomes resid + product
+    assert rel_err(out.cpu().numpy(), (resid.double() + ref).numpy()) < 2e-5
+    dy = torch.randn(T, N, generator=g)
+    dx = torch.empty(T, K, device="cuda")
+    ops.linear_dgrad(dy.cuda(), ops.W2(hi, lo), dx)
+    assert rel_err(dx.cpu().numpy(), (dy.double() @ w.double()).numpy()) < 2e-5
+    if N % 8 == 0:
+        dw = torch.zeros(N, K, device="cuda")
+        ops.linear_wgrad(dy.cuda(), xd, dw)
+        assert rel_err(dw.cpu().numpy(), (dy.double().t() @ x.double()).numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("B,S,H,KVH,D", [(2, 77, 2, 2, 128), (1, 300, 4, 2, 64), (2, 130, 4, 4, 64)])
+def test_fp32_attention_fwd_bwd(B, S, H, KVH, D):
+    from mgen import ops
+    g = torch.Generator().manual_seed(S + H)
+    q = torch.randn(B, S, H, D, generator=g)
+    k = torch.randn(B, S, KVH, D, generator=g)
+    v = torch.randn(B, S, KVH, D, generator=g)
+    do = torch.randn(B, S, H * D, generator=g)
+    qr, kr, vr = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    o = R.causal_attention(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2), D ** -0.5)
+    (o * do).sum().backward()
+    dev = "cuda"
+    qd, kd, vd, dod = [t.reshape(B * S, -1).contiguous().to(dev) for t in (q, k, v, do)]
+    out = torch.empty(B * S, H * D, device=dev)
+    lse = torch.empty(B, H, S, device=dev)
+    ops.attn_fwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), lse, H * D, KVH * D, KVH * D, H * D,
+                 B, S, H, KVH, D, D ** -0.5, f32=True)
+    assert rel_err(out.cpu().numpy(), o.detach().reshape(B * S, -1).numpy()) < 1e-5
+    delta = torch.empty(B, H, S, device=dev)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attn_bwd(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), dod.data_ptr(), lse, delta,
+                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), H * D, KVH * D, KVH * D, H * D, H * D, H * D, KVH * D,
+                 KVH * D, B, S, H, KVH, D, D ** -0.5, f32=True)
+    assert rel_err(dq.cpu().numpy(), qr.grad.reshape(B * S, -1).numpy()) < 1e-5
+    assert rel_err(dk.cpu().numpy(), kr.grad.reshape(B * S, -1).numpy()) < 1e-5
+    assert rel_err(dv.cpu().numpy(), vr.grad.reshape(B * S, -1).numpy()) < 1e-5
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def tiny32(request):
+    from mgen import MidiLM
+    ocfg = CASES[request.param]
+    g = load(request.param)
+    p = tiny_params(ocfg)
+    m = MidiLM(_cfg(ocfg), device="cuda:0", seed=None, compute_dtype=torch.float32)
+    m.load_state_dict(p)
+    return m, ocfg, g, p
+
+
+def test_fp32_logits_loss_grads(tiny32):
+    m, ocfg, g, p = tiny32
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    logits = m(input_ids=ids).logits
+    assert logits.dtype == torch.float32
+    assert rel_err(slim(logits.cpu().numpy()), g["fp32_logits"]) < FP32_TOL
+    m.zero_grad()
+    out = m(input_ids=ids, labels=ids)
+    out.loss.backward()
+    assert abs(float(out.loss.detach()) - float(g["fp32_loss"])) < FP32_TOL * abs(float(g["fp32_loss"]))
+    grads = {n: q.grad.detach().float().cpu().numpy() for n, q in m.named_parameters()}
+    worst = {}
+    for k in g.files:
+        if k.startswith("fp32_grad/"):
+            name = k.split("/", 1)[1]
+            worst[name] = rel_err(slim(grads[name]), g[k])
+    print({k: float("%.2e" % v) for k, v in worst.items()})
+    assert max(worst.values()) < FP32_TOL, worst
+    gn = float(np.sqrt(sum(float((x.astype(np.float64) ** 2).sum()) for x in grads.values())))
+    assert abs(gn - float(g["fp32_grad_norm"])) < FP32_TOL * float(g["fp32_grad_norm"])
+
+
+def test_fp32_padded_batch(tiny32):
+    m, ocfg, g, p = tiny32
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    m.zero_grad()
+    out = m(input_ids=ids, attention_mask=torch.from_numpy(g["pad_mask"]).cuda(),
+            labels=torch.from_numpy(g["pad_labels"]).cuda())
+    out.loss.backward()
+    assert abs(float(out.loss.detach()) - float(g["pad_loss"])) < FP32_TOL * abs(float(g["pad_loss"]))
+    for k in g.files:
+        if k.startswith("pad_grad/"):
+            name = k.split("/", 1)[1]
+            gq = dict(m.named_parameters())[name].grad.detach().float().cpu().numpy()
+            assert rel_err(slim(gq), g[k]) < FP32_TOL, name
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_fp32_training_curve(case):
+    from mgen import MidiLM, get_optim
+    ocfg = CASES[case]
+    g = load(case)
+    m = MidiLM(_cfg(ocfg), device="cuda:0", seed=None, compute_dtype=torch.float32)
+    m.load_state_dict(tiny_params(ocfg))
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    opt, sched = get_optim(m, 5e-5, 12, 20, warmup=10, max_grad_norm=1.0)
+    losses = []
+    for step in range(14):
+        opt.zero_grad()
+        loss = m(input_ids=ids, labels=ids).loss
+        loss.backward()
+        opt.step()
+        sched.step()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g["train_losses"], rtol=FP32_TOL)
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith("after14/"):
+            name = k.split("/", 1)[1]
+            assert rel_err(slim(sd[name].float().cpu().numpy()), g[k]) < FP32_TOL, name
+
+
+def test_fp32_greedy_512_tokens(tiny32):
+    m, ocfg, g, p = tiny32
+    want = torch.from_numpy(g["greedy_tokens"])
+    got = m.generate(want[:, :8].cuda(), max_new_tokens=512, do_sample=False).cpu()
+    same = (got == want)[0, 8:].numpy()
+    if not same.all():
+        first_bad = int(np.argmin(same))
+        assert g["greedy_margin"][first_bad] < 1e-4, (first_bad, g["greedy_margin"][first_bad])
+
+
+def test_fp32_full_size_decoder_c1():
+    """The default decoder at batch 4 x 1024 (the reference's CPU-runnable configuration), scalars and slices."""
+    from mgen import MidiLM
+    g = load("dq_full_c1")
+    ocfg = R.LMConfig()
+    p = R.init_params(ocfg, seed=0)
+    m = MidiLM(_cfg(ocfg, lm_head_chunk_tokens=1024), device="cuda:0", seed=None, compute_dtype=torch.float32)
+    m.load_state_dict(p)
+    del p
+    ids = torch.randint(3, 30000, (4, 1024), generator=torch.Generator().manual_seed(1234))
+    assert np.array_equal(ids[:, :16].numpy(), g["ids_head"])
+    ids = ids.cuda()
+    m.zero_grad()
+    out = m(input_ids=ids, labels=ids)
+    out.loss.backward()
+    assert abs(float(out.loss.detach()) - float(g["loss"])) < FP32_TOL * float(g["loss"])
+    gn = float(torch.linalg.vector_norm(m.flat_grad.double()))
+    assert abs(gn - float(g["grad_norm"])) < 1e-3 * float(g["grad_norm"])
+    gq = m.model.layers[0].self_attn.q_proj.weight.grad[::16, ::16].cpu().numpy()
+    assert rel_err(gq, g["grad_q0_slice"]) < 1e-3
+    with torch.no_grad():
+        lg = m(input_ids=ids[:1]).logits[:, ::97, ::1013].cpu().numpy()
+    assert rel_err(lg, g["logits_slice"][:1]) < FP32_TOL
