@@ -65,16 +65,21 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     }
 }
 
-template <int VPL, typename DyT>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const DyT* __restrict__ dy, const float* __restrict__ x,
-                                                          const float* __restrict__ w,
-                                                          const float* __restrict__ rstd, float* __restrict__ dres,
-                                                          DyT* __restrict__ dres_lp, float* __restrict__ dw,
-                                                          long T, int d, int accumulate) {
-    __shared__ float red[4 * 256 * 4];  // per-wave dw partials for one 256-lane-vector slab
+// Workgroups of 16 waves: the gain gradient costs one atomic per element per WORKGROUP, and thousands of atomics
+// on the same d addresses serialise in L2, so few large workgroups carry the same number of waves as many small ones.
+// (16 waves for rows of up to 512 elements; 4 for longer rows, whose per-lane state needs more than 128 VGPRs.)
+template <int VPL, typename DyT, int BWD_WAVES = (VPL <= 2 ? 16 : 4)>
+__global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* __restrict__ dy,
+                                                                     const float* __restrict__ x,
+                                                                     const float* __restrict__ w,
+                                                                     const float* __restrict__ rstd,
+                                                                     float* __restrict__ dres,
+                                                                     DyT* __restrict__ dres_lp, float* __restrict__ dw,
+                                                                     long T, int d, int accumulate) {
+    __shared__ float red[BWD_WAVES * 64 * 4];  // per-wave dw partials for one 256-element slab of the row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long wave0 = (long)blockIdx.x * 4 + wave;
-    const long nwaves = (long)gridDim.x * 4;
+    const long wave0 = (long)blockIdx.x * BWD_WAVES + wave;
+    const long nwaves = (long)gridDim.x * BWD_WAVES;
     f32x4 wv[VPL], dwv[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const DyT* __restrict_
         __syncthreads();
         if (wave == 0) {
             f32x4 s = *reinterpret_cast<f32x4*>(&red[lane * 4]);
-            for (int k = 1; k < 4; ++k) s += *reinterpret_cast<f32x4*>(&red[(k * 64 + lane) * 4]);
+            for (int k = 1; k < BWD_WAVES; ++k) s += *reinterpret_cast<f32x4*>(&red[(k * 64 + lane) * 4]);
             const int c = (i * 64 + lane) * 4;
             if (c < d)
                 for (int e = 0; e < 4; ++e) atomicAdd(dw + c + e, s[e]);
@@ -159,9 +164,11 @@ extern "C" int mgen_rmsnorm_bwd(const void* dy, const float* x, const float* w, 
                                 hipStream_t stream) {
     MGEN_REQUIRE(dy && x && w && rstd && dres && dw, "mgen_rmsnorm_bwd: null pointer");
     MGEN_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && d <= 2048, "mgen_rmsnorm_bwd: need 0<d<=2048, d%%4==0 (d=%d)", d);
-    long b = (T + 3) / 4;
-    const dim3 grid((int)(b < 1024 ? b : 1024)), block(256);
     DISPATCH_VPL(d, {
+        constexpr int NW = VPL <= 2 ? 16 : 4;
+        const long b = (T + NW - 1) / NW;
+        const dim3 grid((int)(b < 512 ? b : 512));
+        const dim3 block(64 * NW);
         if (dy_bf16)
             hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, bf16>), grid, block, 0, stream, (const bf16*)dy, x, w, rstd,
                                dres, (bf16*)dres_lp, dw, T, d, accumulate);

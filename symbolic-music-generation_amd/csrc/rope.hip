@@ -1,5 +1,6 @@
 // Per-head q/k RMSNorm + rotary position embedding, forward and backward, and the cos/sin table builders.
-// HBM-bound; 16 lanes per (token, head) row of 128 (or 8 lanes per row of 64), 16-byte accesses.
+// HBM-bound: every (token, head) row is read once and written once with 16-byte accesses; the cos/sin values of a
+// token are loaded once into registers and reused for all of its heads.
 //
 // Two pairings:
 //
@@ -43,9 +44,33 @@ __global__ void rope4d_table_kernel(const float* __restrict__ pos4, const float*
     cs[2 * i + 1] = sinf(ang);
 }
 
-// One row = one (token, head). LPR lanes per row, each lane owns 8 consecutive elements.
-// Split-half: the rotation partner of element i < D/2 is i + D/2, held by lane (l ^ LPR/2).
-// Adjacent pairs (IL): the partner of element e is e^1, held by the same lane.
+template <typename IoT> __device__ __forceinline__ void load8(const IoT* p, float* x) {
+    if (sizeof(IoT) == 2) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)p[e];
+    }
+}
+template <typename IoT> __device__ __forceinline__ void store8(IoT* p, const float* x) {
+    if (sizeof(IoT) == 2) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)x[e];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = (IoT)x[e];
+    }
+}
+
+// D/16 lanes per token. A lane owns two groups of 8 elements of every head row of its token, a[0..7] at offset o1 and
+// a[8..15] at offset o2, chosen so that both members of every rotation pair sit in the same lane:
+//   split-half: o1 = 8*sub, o2 = D/2 + 8*sub; element e < 8 pairs with e + 8; both use table entry 8*sub + e
+//   adjacent  : o1 = 16*sub, o2 = 16*sub + 8; element e pairs with e ^ 1; table entry 8*sub + e/2
+// so the lane needs 8 consecutive (cos, sin) entries of its token: 64 bytes, loaded once and used for all heads.
 //  in : qkv  [T, ld_in] (q heads then k heads then v heads; the first HQ+HK+HV heads are touched)
 //  out: qout [T, ld_q], kout [T, ld_k], vout [T, ld_v]
 template <int D, typename IoT, bool FWD, bool IL>
@@ -57,181 +82,130 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const IoT* __restrict_
                                                           int S, long T, int HQ, int HK, int HV, float eps,
                                                           const IoT* __restrict__ raw, long ld_raw,
                                                           float* __restrict__ dwq, float* __restrict__ dwk) {
-    constexpr int LPR = D / 8;             // lanes per row
-    constexpr int RPB = 256 / LPR;         // rows per block per iteration
-    const int sub = threadIdx.x % LPR;     // lane within row
-    const int rib = threadIdx.x / LPR;     // row within block
-    const long NH = HQ + HK + HV;
-    const long nrows = T * NH;
-    const bool hi = sub >= LPR / 2;
-    const int fi = (sub % (LPR / 2)) * 8;  // first frequency index of this lane (split-half)
-    float dwacc_q[8], dwacc_k[8];
+    constexpr int LPR = D / 16;            // lanes per token
+    constexpr int TPB = 256 / LPR;         // tokens per block per iteration
+    const int sub = threadIdx.x % LPR;
+    const int tib = threadIdx.x / LPR;
+    const int NH = HQ + HK + HV;
+    const int o1 = IL ? 16 * sub : 8 * sub;
+    const int o2 = IL ? 16 * sub + 8 : D / 2 + 8 * sub;
+    const bool norm = wq != nullptr;
+    float gq[16], gk[16], dgq[16], dgk[16];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dwacc_q[e] = dwacc_k[e] = 0.f;
+    for (int e = 0; e < 16; ++e) {
+        const int off = e < 8 ? o1 + e : o2 + e - 8;
+        gq[e] = norm ? wq[off] : 1.f;
+        gk[e] = norm ? wk[off] : 1.f;
+        dgq[e] = dgk[e] = 0.f;
+    }
 
-    // the LPR lanes of a row share `row`, so they leave the loop together (the shuffles stay inside a row)
-    for (long row = (long)blockIdx.x * RPB + rib; row < nrows; row += (long)gridDim.x * RPB) {
-        const long t = row / NH;
-        const int hh = (int)(row % NH);
-        const bool isq = hh < HQ;
-        const bool isk = !isq && hh < HQ + HK;
-        const float* w = isq ? wq : (isk ? wk : nullptr);
-        float cosv[8], sinv[8];
-        if (IL) {
-            const float* c = cs + (t * (D / 2) + sub * 4) * 2;
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(c);
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(c + 4);
-            cosv[0] = cosv[1] = v0[0]; sinv[0] = sinv[1] = v0[1];
-            cosv[2] = cosv[3] = v0[2]; sinv[2] = sinv[3] = v0[3];
-            cosv[4] = cosv[5] = v1[0]; sinv[4] = sinv[5] = v1[1];
-            cosv[6] = cosv[7] = v1[2]; sinv[6] = sinv[7] = v1[3];
-        } else {
-            const int p = pos ? pos[t] : (int)(t % S);
-            const float* c = cs + ((long)p * (D / 2) + fi) * 2;
+    // the LPR lanes of a token share `t`, so they leave the loop together (the row reductions stay inside a token)
+    for (long t = (long)blockIdx.x * TPB + tib; t < T; t += (long)gridDim.x * TPB) {
+        float c[8], s[8];
+        {
+            const long trow = IL ? t : (long)(pos ? pos[t] : (int)(t % S));
+            const float* cp = cs + (trow * (D / 2) + 8 * sub) * 2;
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(c + 2 * e);
-                cosv[e] = v[0]; sinv[e] = v[1]; cosv[e + 1] = v[2]; sinv[e + 1] = v[3];
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cp + 2 * e);
+                c[e] = v[0]; s[e] = v[1]; c[e + 1] = v[2]; s[e + 1] = v[3];
             }
         }
-        IoT* outp = isq ? qout + t * ld_q + (long)hh * D + sub * 8
-                        : (isk ? kout + t * ld_k + (long)(hh - HQ) * D + sub * 8
-                               : vout + t * ld_v + (long)(hh - HQ - HK) * D + sub * 8);
-        float wv[8];
+        for (int hh = 0; hh < NH; ++hh) {
+            const bool isq = hh < HQ;
+            const bool isk = !isq && hh < HQ + HK;
+            const bool nrm = norm && (isq || isk);
+            IoT* outp = isq ? qout + t * ld_q + (long)hh * D
+                            : (isk ? kout + t * ld_k + (long)(hh - HQ) * D : vout + t * ld_v + (long)(hh - HQ - HK) * D);
+            float a[16];
+            const IoT* src = in + t * ld_in + (long)hh * D;
+            load8(src + o1, a);
+            load8(src + o2, a + 8);
+            float o[16];
+            if (FWD) {
+                if (nrm) {
+                    float ss = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) wv[e] = w ? w[sub * 8 + e] : 1.f;
-
-        if (FWD) {
-            float x[8];
-            const IoT* src = in + t * ld_in + (long)hh * D + sub * 8;
-            if (sizeof(IoT) == 2) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+                    for (int e = 0; e < 16; ++e) ss += a[e] * a[e];
+                    ss = group_sum<LPR>(ss);
+                    const float rs = rsqrtf(ss / (float)D + eps);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
-            } else {
+                    for (int e = 0; e < 16; ++e) {
+                        float xn = a[e] * rs;
+                        if (sizeof(IoT) == 2) xn = round_bf(xn);
+                        a[e] = (isq ? gq[e] : gk[e]) * xn;
+                    }
+                }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = (float)src[e];
-            }
-            float y[8];
-            if (w) {
-                float ss = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-                ss = group_sum<LPR>(ss);
-                const float rs = rsqrtf(ss / (float)D + eps);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float xn = x[e] * rs;
-                    if (sizeof(IoT) == 2) xn = round_bf(xn);
-                    y[e] = wv[e] * xn;
+                for (int e = 0; e < 16; ++e) {
+                    const int pe = IL ? (e ^ 1) : (e ^ 8);                 // partner element
+                    const int ci = IL ? (e >> 1) : (e & 7);                // table entry
+                    const bool second = IL ? (e & 1) : (e >= 8);           // second member of its pair
+                    o[e] = second ? (a[e] * c[ci] + a[pe] * s[ci]) : (a[e] * c[ci] - a[pe] * s[ci]);
                 }
             } else {
+                // backward: `in` holds d(out) (same head order); the result may be written over it (each row is read
+                // and written by the same lanes). `raw` = forward input. Transpose of the rotation:
+                // dy1 = d1*cos + d2*sin ; dy2 = d2*cos - d1*sin
+                float dy[16];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = x[e];
-            }
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (IL) {
-                    o[e] = (e & 1) ? (y[e] * cosv[e] + y[e ^ 1] * sinv[e]) : (y[e] * cosv[e] - y[e ^ 1] * sinv[e]);
-                } else {
-                    const float other = __shfl_xor(y[e], LPR / 2, 64);
-                    o[e] = hi ? (y[e] * cosv[e] + other * sinv[e]) : (y[e] * cosv[e] - other * sinv[e]);
+                for (int e = 0; e < 16; ++e) {
+                    const int pe = IL ? (e ^ 1) : (e ^ 8);
+                    const int ci = IL ? (e >> 1) : (e & 7);
+                    const bool second = IL ? (e & 1) : (e >= 8);
+                    dy[e] = second ? (a[e] * c[ci] - a[pe] * s[ci]) : (a[e] * c[ci] + a[pe] * s[ci]);
                 }
-            }
-            if (sizeof(IoT) == 2) {
-                bf16x8 v;
+                if (nrm) {
+                    float x[16];
+                    const IoT* rsrc = raw + t * ld_raw + (long)hh * D;
+                    load8(rsrc + o1, x);
+                    load8(rsrc + o2, x + 8);
+                    float ss = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)o[e];
-                *reinterpret_cast<bf16x8*>(outp) = v;
-            } else {
+                    for (int e = 0; e < 16; ++e) ss += x[e] * x[e];
+                    ss = group_sum<LPR>(ss);
+                    const float rs = rsqrtf(ss / (float)D + eps);
+                    float dot = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) outp[e] = (IoT)o[e];
-            }
-        } else {
-            // backward: `in` holds d(out) ([T, ld_in], same head order); result written to qout/kout/vout (may
-            // alias `in`: each row is read and written by the same lanes). `raw` = forward input.
-            float dout[8];
-            const IoT* src = in + t * ld_in + (long)hh * D + sub * 8;
-            if (sizeof(IoT) == 2) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+                    for (int e = 0; e < 16; ++e) {
+                        x[e] *= rs;                                        // normalised input
+                        const float gx = dy[e] * (isq ? gq[e] : gk[e]);
+                        dot += gx * x[e];
+                        if (isq) dgq[e] += dy[e] * x[e];
+                        else dgk[e] += dy[e] * x[e];
+                        o[e] = gx;
+                    }
+                    dot = group_sum<LPR>(dot) / (float)D;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dout[e] = (float)v[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dout[e] = (float)src[e];
-            }
-            float dy[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                // transpose of the rotation: dy1 = d1*cos + d2*sin ; dy2 = d2*cos - d1*sin
-                if (IL) {
-                    dy[e] = (e & 1) ? (dout[e] * cosv[e] - dout[e ^ 1] * sinv[e])
-                                    : (dout[e] * cosv[e] + dout[e ^ 1] * sinv[e]);
-                } else {
-                    const float other = __shfl_xor(dout[e], LPR / 2, 64);
-                    dy[e] = hi ? (dout[e] * cosv[e] - other * sinv[e]) : (dout[e] * cosv[e] + other * sinv[e]);
-                }
-            }
-            float dx[8];
-            if (w) {
-                float x[8];
-                const IoT* rsrc = raw + t * ld_raw + (long)hh * D + sub * 8;
-                if (sizeof(IoT) == 2) {
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(rsrc);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
+                    for (int e = 0; e < 16; ++e) o[e] = (o[e] - x[e] * dot) * rs;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = (float)rsrc[e];
+                    for (int e = 0; e < 16; ++e) o[e] = dy[e];
                 }
-                float ss = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-                ss = group_sum<LPR>(ss);
-                const float rs = rsqrtf(ss / (float)D + eps);
-                float dot = 0.f;
-                float xh[8], gx[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    xh[e] = x[e] * rs;
-                    gx[e] = dy[e] * wv[e];
-                    dot += gx[e] * xh[e];
-                    if (isq) dwacc_q[e] += dy[e] * xh[e];
-                    else dwacc_k[e] += dy[e] * xh[e];
-                }
-                dot = group_sum<LPR>(dot) / (float)D;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dx[e] = (gx[e] - xh[e] * dot) * rs;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dx[e] = dy[e];
             }
-            if (sizeof(IoT) == 2) {
-                bf16x8 v;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16)dx[e];
-                *reinterpret_cast<bf16x8*>(outp) = v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) outp[e] = (IoT)dx[e];
-            }
+            store8(outp + o1, o);
+            store8(outp + o2, o + 8);
         }
     }
-    if (!FWD && wq) {
-        // reduce the per-thread gain gradients over the rows of the block (threads with equal `sub`)
-        __shared__ float red[2][256][8];
+    if (!FWD && norm) {
+        // reduce the per-lane gain gradients over the tokens of the block (lanes with equal `sub`)
+        __shared__ float red[256][17];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red[0][threadIdx.x][e] = dwacc_q[e];
-            red[1][threadIdx.x][e] = dwacc_k[e];
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 * D) {
-            const int which = threadIdx.x / D, el = threadIdx.x % D;
-            float s = 0.f;
-            for (int rr = 0; rr < RPB; ++rr) s += red[which][rr * LPR + el / 8][el % 8];
-            atomicAdd((which ? dwk : dwq) + el, s);
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[threadIdx.x][e] = which ? dgk[e] : dgq[e];
+            __syncthreads();
+            if (threadIdx.x < D) {
+                const int el = threadIdx.x;
+                int ls, le;   // owning lane and slot of element el
+                if (IL) { ls = el / 16; le = el % 16; }
+                else if (el < D / 2) { ls = el / 8; le = el % 8; }
+                else { ls = (el - D / 2) / 8; le = 8 + (el - D / 2) % 8; }
+                float acc = 0.f;
+                for (int tt = 0; tt < TPB; ++tt) acc += red[tt * LPR + ls][le];
+                atomicAdd((which ? dwk : dwq) + el, acc);
+            }
         }
     }
 }
@@ -261,9 +235,8 @@ static int qknorm_rope_launch(const void* in, long ld_in, void* qout, void* kout
                               long ld_v, const float* wq, const float* wk, const float* cs, const int* pos, int S,
                               long T, int HQ, int HK, int HV, int D, float eps, const void* raw, long ld_raw,
                               float* dwq, float* dwk, int is_bf16, hipStream_t stream, const char* what) {
-    const long nrows = T * (HQ + HK + HV);
-    const int rpb = 256 / (D / 8);
-    long nb = (nrows + rpb - 1) / rpb;
+    const int tpb = 256 / (D / 16);
+    long nb = (T + tpb - 1) / tpb;
     if (nb > 4096) nb = 4096;
 #define LAUNCH(DD, TT)                                                                                         \
     hipLaunchKernelGGL((qknorm_rope_kernel<DD, TT, FWD, IL>), dim3((unsigned)nb), dim3(256), 0, stream,        \

@@ -1,0 +1,62 @@
+"""Time the HBM-bound kernels of one decoder layer at the training shape (GPU box only):
+q/k-norm + RoPE forward and backward, RMSNorm backward, SwiGLU forward and backward."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
+from mgen import ops  # noqa: E402
+
+B, S, H, Dh, d, I = 32, 2048, 8, 128, 512, 2048
+T = B * S
+dev = "cuda"
+bf = torch.bfloat16
+NQ, QK = 3 * H * Dh, 2 * H * Dh
+
+
+def timeit(name, fn, nbytes, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    print(f"{name:22s} {us:8.1f} us  {nbytes / us / 1e6:7.2f} TB/s")
+
+
+qkv = torch.randn(T, NQ, device=dev).to(bf)
+qk = torch.empty(T, QK, dtype=bf, device=dev)
+wq = torch.ones(Dh, device=dev)
+wk = torch.ones(Dh, device=dev)
+inv = 1.0 / (1e6 ** (torch.arange(0, Dh, 2, dtype=torch.float) / Dh))
+cs = ops.rope_table(inv.to(dev), S)
+timeit("qknorm_rope_fwd", lambda: ops.qknorm_rope_fwd(qkv, NQ, qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, QK, QK, wq,
+                                                       wk, cs, None, S, T, H, H, Dh, 1e-6), T * QK * 2 * 2)
+dqkv = torch.randn(T, NQ, device=dev).to(bf)
+dwq = torch.zeros(Dh, device=dev)
+dwk = torch.zeros(Dh, device=dev)
+p = dqkv.data_ptr()
+timeit("qknorm_rope_bwd", lambda: ops.qknorm_rope_bwd(p, NQ, p, p + 2 * H * Dh, NQ, NQ, qkv, NQ, wq, wk, dwq, dwk, cs,
+                                                       None, S, T, H, H, Dh, 1e-6), T * QK * 2 * 3)
+x = torch.randn(T, d, device=dev)
+w = torch.ones(d, device=dev)
+dy = torch.randn(T, d, device=dev).to(bf)
+rstd = torch.rand(T, device=dev) + 0.5
+dres = torch.zeros(T, d, device=dev)
+dlp = torch.empty(T, d, dtype=bf, device=dev)
+dw = torch.zeros(d, device=dev)
+timeit("rmsnorm_bwd", lambda: ops.rmsnorm_bwd(dy, x, w, rstd, dres, dlp, dw, True), T * d * (2 + 4 + 8 + 2))
+y = torch.empty(T, d, dtype=bf, device=dev)
+timeit("rmsnorm_fwd", lambda: ops.rmsnorm_fwd(x, w, y, rstd, 1e-6), T * d * (4 + 2))
+gu = torch.randn(T, 2 * I, device=dev).to(bf)
+act = torch.empty(T, I, dtype=bf, device=dev)
+timeit("swiglu_fwd", lambda: ops.swiglu_fwd(gu, act), T * I * 2 * 3)
+dact = torch.randn(T, I, device=dev).to(bf)
+dgu = torch.empty(T, 2 * I, dtype=bf, device=dev)
+timeit("swiglu_bwd", lambda: ops.swiglu_bwd(gu, dact, dgu), T * I * 2 * 5)
