@@ -38,6 +38,18 @@ int mgen_device_info(int device, char* name, int name_len);
 int mgen_gemm_bf16(const void* A, const void* B, void* C, const void* resid, int M, int N, int K, long lda, long ldb,
                    long ldc, long ldr, int transA, int transB, int out_mode, float alpha, mgen_stream_t stream);
 
+/* Split-K without atomics for products with few output tiles (the decode path: M = number of streams). The K range
+ * is cut into nslabs slices (mgen_gemm_slab_count(K, max_slabs) gives a valid count: 128 reduction indices per slice,
+ * more when that would exceed max_slabs); slice z stores its fp32 partial product [M][N] at slabs + z*M*N.
+ * mgen_slab_resid_rmsnorm is the consumer for the two residual projections of a decoder layer
+ * (TF models/qwen3/modeling_qwen3.py:294-323): h_out = resid + sum_z slab_z (the sum rounded to bf16 first when
+ * round_bf16), then, when w and y are given, y = bf16(w * h_out * rsqrt(mean(h_out^2) + eps)) — the norm that follows. */
+int mgen_gemm_slab_count(int K, int max_slabs);
+int mgen_gemm_bf16_slabs(const void* A, const void* B, float* slabs, int M, int N, int K, long lda, long ldb,
+                         int transA, int transB, int nslabs, mgen_stream_t stream);
+int mgen_slab_resid_rmsnorm(const float* slabs, int nslabs, long slab_stride, const float* resid, float* h_out,
+                            const float* w, void* y, long T, int d, float eps, int round_bf16, mgen_stream_t stream);
+
 /* ---- RMSNorm over the fp32 residual stream -------------------------------------------------------------------
  * Qwen3RMSNorm.forward, reference src/model/modeling.py:60-65. y is bf16 (out_bf16=1) or fp32; rstd[T] is saved for
  * the backward. d % 4 == 0, d <= 2048. */

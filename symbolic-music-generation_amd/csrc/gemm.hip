@@ -32,6 +32,7 @@ struct GemmArgs {
     float alpha;
     int nbm, nbn;
     int splitk, kper;  // K is cut into `splitk` slices of `kper` elements (kper % BK == 0)
+    long slab_stride;  // fp32 store modes: slice z writes its partial product at C + z * slab_stride (0: one output)
 };
 
 // ---- global -> register staging of one operand tile (4 x 16 bytes per thread) -----------------------------
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
     const int wg = wid / g.splitk;
     const int kbeg = (wid % g.splitk) * g.kper;
     const int kend = min(g.K, kbeg + g.kper);
+    const long coff = (long)(wid % g.splitk) * g.slab_stride;
     constexpr int GROUP = 8;
     const int width = GROUP * g.nbn;
     const int grp = wg / width;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
         // fp32 output through LDS, 32 rows at a time: [32 rows][256 bytes] per wave, 16-byte chunks XOR-swizzled by
         // row; then whole 256-byte row segments are combined with the old value / residual and stored, 16 B per lane.
         char* st = smem + wave * 8192;
-        float* C = reinterpret_cast<float*>(g.C);
+        float* C = reinterpret_cast<float*>(g.C) + coff;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (i) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
                         for (int e = 0; e < 4 && n + e < g.N; ++e) c[e] = (bf16)v[e];
                     }
                 } else {
-                    float* c = reinterpret_cast<float*>(g.C) + (long)m * g.ldc + n;
+                    float* c = reinterpret_cast<float*>(g.C) + coff + (long)m * g.ldc + n;
                     if (MODE == OUT_F32_RESID_BF16ROUND || MODE == OUT_F32_RESID) {
                         const float* r = g.R + (long)m * g.ldr + n;
                         for (int e = 0; e < 4; ++e)
@@ -387,7 +389,7 @@ int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
 
 static int gemm_impl(const void* A, const void* B, void* C, const void* resid, const void* bias, int M, int N, int K,
                      long lda, long ldb, long ldc, long ldr, int transA, int transB, int out_mode, float alpha,
-                     hipStream_t stream) {
+                     hipStream_t stream, int slabs = 0, long slab_stride = 0) {
     MGEN_REQUIRE(A && B && C, "mgen_gemm_bf16: null operand");
     if (bias)
         MGEN_REQUIRE(alpha == 1.0f && out_mode != OUT_F32_ACC,
@@ -413,6 +415,7 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     g.nbm = (M + BM - 1) / BM; g.nbn = (N + BN - 1) / BN;
     MGEN_REQUIRE(out_mode >= 0 && out_mode <= OUT_F32_RESID, "mgen_gemm_bf16: unknown out_mode %d", out_mode);
     g.splitk = 1;
+    g.slab_stride = 0;
     g.kper = ((K + BK - 1) / BK) * BK;
     // An accumulating product with few output tiles and a long reduction (weight gradients: K = tokens) is cut
     // along K so that the chip is filled; the slices add their tiles with fp32 atomics.
@@ -429,6 +432,16 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
             out_mode = OUT_F32_ATOMIC;
         }
     }
+    if (slabs > 1) {
+        // deterministic split-K: slice z stores its partial product (fp32) at C + z * slab_stride
+        const int ksteps = (K + BK - 1) / BK;
+        const int steps_per = (ksteps + slabs - 1) / slabs;
+        MGEN_REQUIRE((ksteps + steps_per - 1) / steps_per == slabs,
+                     "mgen_gemm_bf16_slabs: %d slabs do not divide %d K steps evenly enough", slabs, ksteps);
+        g.kper = steps_per * BK;
+        g.splitk = slabs;
+        g.slab_stride = slab_stride;
+    }
     MGEN_REQUIRE(tiles * g.splitk < (1L << 31), "mgen_gemm_bf16: grid too large");
     const bool glds = (K % BK) == 0;
 #define MGEN_GEMM_GO(TA_, TB_) \
@@ -444,6 +457,23 @@ extern "C" int mgen_gemm_bf16(const void* A, const void* B, void* C, const void*
                               long lda, long ldb, long ldc, long ldr, int transA, int transB, int out_mode,
                               float alpha, hipStream_t stream) {
     return gemm_impl(A, B, C, resid, nullptr, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_mode, alpha, stream);
+}
+
+// Split-K without atomics for products with few output tiles (decode: M = number of streams): the K range is cut
+// into `nslabs` slices and slice z stores its fp32 partial product [M][N] (row stride N) at slabs + z * M * N.
+// mgen_gemm_slab_count gives the number of slices to ask for; the consumer sums them in slice order.
+extern "C" int mgen_gemm_slab_count(int K, int max_slabs) {
+    const int ksteps = (K + BK - 1) / BK;
+    int steps_per = 2;  // 128 reduction indices per slice
+    while ((ksteps + steps_per - 1) / steps_per > max_slabs) ++steps_per;
+    return (ksteps + steps_per - 1) / steps_per;
+}
+
+extern "C" int mgen_gemm_bf16_slabs(const void* A, const void* B, float* slabs, int M, int N, int K, long lda, long ldb,
+                                    int transA, int transB, int nslabs, hipStream_t stream) {
+    MGEN_REQUIRE(nslabs >= 1 && N % 4 == 0, "mgen_gemm_bf16_slabs: need nslabs >= 1 and N %% 4 == 0");
+    return gemm_impl(A, B, slabs, nullptr, nullptr, M, N, K, lda, ldb, N, 0, transA, transB, OUT_F32, 1.0f, stream,
+                     nslabs, (long)M * N);
 }
 
 // Same product with a bias row (bf16 [N]) added to the fp32 accumulators before the output rounding: the fused

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libmgen_hip.so")
 # name -> argument types (every function returns int, 0 = ok), in the order of include/mgen.h
 SIGNATURES = {
     "mgen_gemm_bf16": [P, P, P, P, I, I, I, L, L, L, L, I, I, I, F, P],
+    "mgen_gemm_bf16_slabs": [P, P, P, I, I, I, L, L, I, I, I, P],
+    "mgen_slab_resid_rmsnorm": [P, I, L, P, P, P, P, L, I, F, I, P],
     "mgen_rmsnorm_fwd": [P, P, P, P, L, I, F, I, P],
     "mgen_rmsnorm_bwd": [P, P, P, P, P, P, P, L, I, I, I, P],
     "mgen_rope_table": [P, P, I, I, P],
@@ -81,6 +83,8 @@ def lib():
         l.mgen_last_error.argtypes = []
         l.mgen_version.restype = ctypes.c_int
         l.mgen_sumsq_partial_count.restype = ctypes.c_int
+        l.mgen_gemm_slab_count.argtypes = [I, I]
+        l.mgen_gemm_slab_count.restype = ctypes.c_int
         l.mgen_attn_decode_workspace.argtypes = [I, I, I, I]
         l.mgen_attn_decode_workspace.restype = ctypes.c_long
         l.mgen_device_info.argtypes = [I, ctypes.c_char_p, I]

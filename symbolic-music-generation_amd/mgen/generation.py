@@ -49,6 +49,10 @@ class _DecodeBuffers:
         self.ldv = (cfg.vocab_size + 7) // 8 * 8
         self.logits = torch.empty(B, self.ldv, dtype=bf, device=dev)
         self.next = torch.empty(B, dtype=torch.int64, device=dev)
+        # split-K slabs of the two residual projections (K = H*Dh and K = I)
+        self.ns_o = ops.gemm_slab_count(H * Dh)
+        self.ns_d = ops.gemm_slab_count(I)
+        self.slabs = torch.empty(max(self.ns_o, self.ns_d), B, d, dtype=f32, device=dev)
         if cfg.pos4d:
             self.rot = torch.empty(B, cfg.qkv_width, dtype=bf, device=dev)
             self.pairs = torch.empty(B, 16, dtype=bf, device=dev)
@@ -78,25 +82,29 @@ class GenerationMixin:
         kv_len = lens[t + 1]   # int32 [B] = t + 1
         nsplit = self._decode_split(B, t + 1)
         h = buf.h0
+        eps = cfg.rms_norm_eps
+        L = cfg.num_hidden_layers
         ops.embedding_fwd(tokens, self.model.embed_tokens.weight, h, self._err_flag)
+        ops.rmsnorm_fwd(h, self._layers[0].w_ln1, buf.x, None, eps)
+        # The two residual projections have few output tiles at M = B rows: they run split along K into fp32 slabs,
+        # and one kernel sums the slabs, adds the residual and applies the norm that follows.
         for l, v in enumerate(self._layers):
-            ops.rmsnorm_fwd(h, v.w_ln1, buf.x, None, cfg.rms_norm_eps)
             ops.linear_fwd(buf.x, v.s_qkv, buf.qkv)
             qp = buf.qk.data_ptr()
-            ops.qknorm_rope_fwd(buf.qkv, NQ, qp, qp + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, 1, B, H, KVH, Dh,
-                                cfg.rms_norm_eps)
+            ops.qknorm_rope_fwd(buf.qkv, NQ, qp, qp + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, 1, B, H, KVH, Dh, eps)
             ops.kv_append(qp + 2 * H * Dh, buf.qkv.data_ptr() + 2 * QK, QK, NQ, cache.k[l], cache.v[l], pos, B, 1, KVH,
                           Dh, cache.max_len)
             ops.attn_decode(qp, QK, cache.k[l], cache.v[l], kv_len, buf.att, H * Dh, ws, B, H, KVH, Dh, cache.max_len,
                             nsplit, scale)
-            ops.linear_fwd(buf.att, v.s_o, buf.h1, ops.OUT_F32_RESID_BF16ROUND, h)
-            ops.rmsnorm_fwd(buf.h1, v.w_ln2, buf.x, None, cfg.rms_norm_eps)
+            ops.linear_slabs(buf.att, v.s_o, buf.slabs, buf.ns_o)
+            ops.slab_resid_rmsnorm(buf.slabs, buf.ns_o, h, buf.h1, v.w_ln2, buf.x, eps)
             ops.linear_fwd(buf.x, v.s_gu, buf.gu)
             ops.swiglu_fwd(buf.gu, buf.act)
+            ops.linear_slabs(buf.act, v.s_down, buf.slabs, buf.ns_d)
             nxt = buf.h2 if h is buf.h0 else buf.h0
-            ops.linear_fwd(buf.act, v.s_down, nxt, ops.OUT_F32_RESID_BF16ROUND, buf.h1)
+            w_next = self._layers[l + 1].w_ln1 if l + 1 < L else self.model.norm.weight
+            ops.slab_resid_rmsnorm(buf.slabs, buf.ns_d, buf.h1, nxt, w_next, buf.x, eps)
             h = nxt
-        ops.rmsnorm_fwd(h, self.model.norm.weight, buf.x, None, cfg.rms_norm_eps)
         W = self._view(self.flat_shadow, self._lm_head_name())
         ops.gemm(buf.x, W, buf.logits, B, cfg.vocab_size, d, d, W.stride(0), buf.ldv)
         return buf.logits
@@ -232,23 +240,26 @@ class GenerationMixin:
         ops.fill_rows(self.model.embed_vector, h)
         qp = buf.rot.data_ptr()
         kp, vp = qp + 2 * H * Dh, qp + 2 * QK
+        eps = cfg.rms_norm_eps
+        L = cfg.num_hidden_layers
+        ops.rmsnorm_fwd(h, self._layers[0].w_ln1, buf.x, None, eps)
         for l, v in enumerate(self._layers):
-            ops.rmsnorm_fwd(h, v.w_ln1, buf.x, None, cfg.rms_norm_eps)
             ops.linear_fwd(buf.x, v.s_qkv, buf.qkv)
             ops.qkvnorm_rope4d_fwd(buf.qkv.data_ptr(), NQ, qp, kp, vp, NQ, NQ, NQ, v.w_qn, v.w_kn, cs, B, H, KVH, KVH,
-                                   Dh, cfg.rms_norm_eps)
+                                   Dh, eps)
             ops.kv_append(kp, vp, NQ, NQ, cache.k[l], cache.v[l], pos, B, 1, KVH, Dh, cache.max_len)
             ops.attn_decode(qp, NQ, cache.k[l], cache.v[l], kv_len, buf.att, H * Dh, ws, B, H, KVH, Dh, cache.max_len,
                             nsplit, scale)
             ops.rotate4d(buf.att, buf.att, cs, B, H, Dh, inverse=True)
-            ops.linear_fwd(buf.att, v.s_o, buf.h1, ops.OUT_F32_RESID_BF16ROUND, h)
-            ops.rmsnorm_fwd(buf.h1, v.w_ln2, buf.x, None, cfg.rms_norm_eps)
+            ops.linear_slabs(buf.att, v.s_o, buf.slabs, buf.ns_o)
+            ops.slab_resid_rmsnorm(buf.slabs, buf.ns_o, h, buf.h1, v.w_ln2, buf.x, eps)
             ops.linear_fwd(buf.x, v.s_gu, buf.gu)
             ops.swiglu_fwd(buf.gu, buf.act)
+            ops.linear_slabs(buf.act, v.s_down, buf.slabs, buf.ns_d)
             nxt = buf.h2 if h is buf.h0 else buf.h0
-            ops.linear_fwd(buf.act, v.s_down, nxt, ops.OUT_F32_RESID_BF16ROUND, buf.h1)
+            w_next = self._layers[l + 1].w_ln1 if l + 1 < L else self.model.norm.weight
+            ops.slab_resid_rmsnorm(buf.slabs, buf.ns_d, buf.h1, nxt, w_next, buf.x, eps)
             h = nxt
-        ops.rmsnorm_fwd(h, self.model.norm.weight, buf.x, None, cfg.rms_norm_eps)
         W = self._view(self.flat_shadow, "lm_head.weight")
         ops.gemm(buf.x, W, buf.pairs, B, 16, d, d, W.stride(0), 16)
         ops.cos4d_fwd_bwd(buf.pairs, None, None, 1.0, buf.pred, None, None)

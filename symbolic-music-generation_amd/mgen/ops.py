@@ -84,6 +84,25 @@ def gemm_any(a, b, c, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_
     gemm(al, bh, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, OUT_F32_ACC)
 
 
+def gemm_slab_count(K, max_slabs=16):
+    from ._lib import lib
+    return lib().mgen_gemm_slab_count(K, max_slabs)
+
+
+def linear_slabs(x, w, slabs, nslabs):
+    """slabs[z, T, N] = partial products of x[T,K] @ w[N,K]^T over the z-th K slice (fp32, no atomics)."""
+    _need_gpu(x, w, slabs)
+    T, K = x.shape
+    N = w.shape[0]
+    call("mgen_gemm_bf16_slabs", _p(x), _p(w), _p(slabs), T, N, K, x.stride(0), w.stride(0), 0, 0, nslabs, _stream())
+
+
+def slab_resid_rmsnorm(slabs, nslabs, resid, h_out, w, y, eps, round_bf16=True):
+    T, d = resid.shape
+    call("mgen_slab_resid_rmsnorm", _p(slabs), nslabs, T * d, _p(resid), _p(h_out), _p(w), _p(y), T, d, eps,
+         int(round_bf16), _stream())
+
+
 def linear_fwd(x, w, out, out_mode=OUT_BF16, resid=None):
     """out[T,N] = x[T,K] @ w[N,K]^T for contiguous 2-D tensors."""
     T, K = x.shape

@@ -232,3 +232,30 @@ def test_generate_eos_and_length_semantics(tiny):
         m.generate(prompt.cuda(), max_new_tokens=4, do_sample=True, temperature=0.0)
     with pytest.raises(RuntimeError):
         m.generate(prompt, max_new_tokens=4)
+
+
+@pytest.mark.parametrize("B,K,N", [(256, 1024, 512), (2, 256, 256), (37, 768, 1536)])
+def test_split_k_slabs_and_fused_residual_norm(ops, B, K, N):
+    """Decode-path residual projection: partial products in fp32 slabs, then one kernel sums them in order, rounds the
+    projection to bf16, adds the residual and applies the following RMSNorm."""
+    g = torch.Generator().manual_seed(B + K)
+    x = bf(torch.randn(B, K, generator=g))
+    w = bf(torch.randn(N, K, generator=g) * 0.05)
+    resid = torch.randn(B, N, generator=g)
+    gain = 1 + 0.1 * torch.randn(N, generator=g)
+    ns = ops.gemm_slab_count(K)
+    assert 1 <= ns <= 16
+    slabs = torch.empty(ns, B, N, device=dev())
+    ops.linear_slabs(x.to(dev()), w.to(dev()), slabs, ns)
+    ref = x.float() @ w.float().t()
+    assert rel_err(slabs.sum(0).cpu().numpy(), ref.numpy()) < 1e-5
+    h_out = torch.empty(B, N, device=dev())
+    y = torch.empty(B, N, dtype=torch.bfloat16, device=dev())
+    ops.slab_resid_rmsnorm(slabs, ns, resid.to(dev()), h_out, gain.to(dev()), y, 1e-6)
+    h_ref = resid + bf(slabs.sum(0).cpu()).float()
+    # the kernel sums the slabs in slice order; torch's sum may differ in the last bit before the bf16 rounding
+    assert rel_err(h_out.cpu().numpy(), h_ref.numpy()) < 5e-3
+    y_ref = R.rmsnorm(h_out.cpu(), gain, 1e-6)
+    assert rel_err(y.float().cpu().numpy(), y_ref.numpy()) < 5e-3
+    ops.slab_resid_rmsnorm(slabs, ns, resid.to(dev()), h_out, None, None, 1e-6, round_bf16=False)
+    assert rel_err(h_out.cpu().numpy(), (resid + ref).numpy()) < 1e-5
