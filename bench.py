@@ -64,25 +64,37 @@ def cpu_baseline(cfg, S, seconds_budget=25.0):
                       f"best of {len(times)} runs, {best:.2f} s/step"}
 
 
-def bench_decode(model, cfg, streams, new_tokens, dev):
-    """Batched sampling (BASELINE.json configs[3] shape): `streams` concurrent KV-cache decode streams, prompt = one
-    BOS token, temperature 0.97, top-p 0.95, no top-k, EOS disabled, Philox noise seed 1234. Reported per GPU."""
-    prompt = torch.full((streams, 1), cfg.bos_token_id, dtype=torch.int64, device=dev)
+def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
+    """Batched sampling (BASELINE.json configs[3] shape: 256 streams, contexts up to 4096): `streams` concurrent
+    KV-cache decode streams on a random prompt of `prompt_len` tokens, temperature 0.97, top-p 0.95, no top-k, EOS
+    disabled, Philox noise seed 1234. The decode rate is (time of prefill + N steps) - (time of prefill + 1 step) over
+    N - 1 steps; algorithmic bytes per step = bf16 weights + the [streams, V] bf16 logits + the KV cache of the
+    context. Reported per GPU."""
+    g = torch.Generator().manual_seed(99)
+    prompt = torch.randint(3, 30000, (streams, prompt_len), generator=g).to(dev)
     kw = dict(do_sample=True, temperature=0.97, top_k=0, top_p=0.95, seed=1234)
-    model.generate(prompt, max_new_tokens=8, **kw)  # warm-up
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = model.generate(prompt, max_new_tokens=new_tokens, **kw)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    steps = new_tokens
+    model.generate(prompt, max_new_tokens=4, **kw)  # warm-up
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = model.generate(prompt, max_new_tokens=n, **kw)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, o
+
+    t1, _ = run(1)
+    tn, out = run(new_tokens)
+    steps = new_tokens - 1
+    dt = tn - t1
     L, KVH, Dh = cfg.num_hidden_layers, cfg.num_key_value_heads, cfg.head_dim
     kv_tok = 2 * L * KVH * Dh * 2
     weights = 2 * (sum(p.numel() for p in model.parameters()))
-    ctx_sum = sum(range(1, steps + 1))  # keys read at step t = t (prompt of 1 token)
+    ctx_sum = sum(range(prompt_len + 1, prompt_len + steps + 1))  # keys read by the decode steps
     bytes_total = steps * (weights + streams * cfg.vocab_size * 2) + streams * ctx_sum * kv_tok
-    return {"streams": streams, "new_tokens": new_tokens, "tokens_per_s_per_gpu": round(streams * steps / dt, 1),
-            "ms_per_step": round(dt / steps * 1e3, 3), "algorithmic_GBps": round(bytes_total / dt / 1e9, 1),
+    return {"streams": streams, "prompt_len": prompt_len, "new_tokens": new_tokens,
+            "tokens_per_s_per_gpu": round(streams * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "prefill_tokens_per_s": round(streams * prompt_len / t1, 1),
+            "algorithmic_GBps": round(bytes_total / dt / 1e9, 1),
             "hbm_frac": round(bytes_total / dt / 1e9 / PEAK_HBM_GBS, 4),
             "sampling": "T=0.97 top_p=0.95 top_k=off philox(seed 1234)", "out_shape": list(out.shape)}
 
@@ -91,6 +103,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--decode-streams", type=int, default=256)
     ap.add_argument("--decode-tokens", type=int, default=256, help="0 disables the decode measurement")
+    ap.add_argument("--decode-prompt", type=int, default=1792,
+                    help="prompt length of the decode measurement (contexts run from here to +decode-tokens)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
@@ -186,7 +200,8 @@ def main():
             del trainer, batch
             model.zero_grad()
             torch.cuda.empty_cache()
-            out["decode"] = bench_decode(model, cfg, args.decode_streams, args.decode_tokens, dev)
+            out["decode"] = bench_decode(model, cfg, args.decode_streams, args.decode_prompt, args.decode_tokens, dev)
+            out["decode_short_context"] = bench_decode(model, cfg, args.decode_streams, 1, args.decode_tokens, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(out))

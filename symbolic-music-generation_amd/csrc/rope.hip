@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const IoT* __restrict_
                 c[e] = v[0]; s[e] = v[1]; c[e + 1] = v[2]; s[e + 1] = v[3];
             }
         }
-        for (int hh = 0; hh < NH; ++hh) {
+        // gridDim.y > 1 (few tokens: decode) spreads the heads of a token over workgroups
+        for (int hh = blockIdx.y; hh < NH; hh += gridDim.y) {
             const bool isq = hh < HQ;
             const bool isk = !isq && hh < HQ + HK;
             const bool nrm = norm && (isq || isk);
@@ -238,8 +239,10 @@ static int qknorm_rope_launch(const void* in, long ld_in, void* qout, void* kout
     const int tpb = 256 / (D / 16);
     long nb = (T + tpb - 1) / tpb;
     if (nb > 4096) nb = 4096;
+    const int nh = HQ + HK + HV;
+    const unsigned ny = nb >= 512 ? 1u : (unsigned)(nh < 32 ? nh : 32);   // few tokens: one head (group) per workgroup
 #define LAUNCH(DD, TT)                                                                                         \
-    hipLaunchKernelGGL((qknorm_rope_kernel<DD, TT, FWD, IL>), dim3((unsigned)nb), dim3(256), 0, stream,        \
+    hipLaunchKernelGGL((qknorm_rope_kernel<DD, TT, FWD, IL>), dim3((unsigned)nb, ny), dim3(256), 0, stream,    \
                        (const TT*)in, ld_in, (TT*)qout, (TT*)kout, (TT*)vout, ld_q, ld_k, ld_v, wq, wk, cs,    \
                        pos, S, T, HQ, HK, HV, eps, (const TT*)raw, ld_raw, dwq, dwk)
     if (D == 128 && is_bf16) LAUNCH(128, bf16);

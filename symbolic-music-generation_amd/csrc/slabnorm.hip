@@ -10,13 +10,14 @@
 namespace {
 
 template <int VPL>
-__global__ __launch_bounds__(256) void slab_resid_rmsnorm_kernel(const float* __restrict__ slabs, int nslabs,
+__global__ __launch_bounds__(64) void slab_resid_rmsnorm_kernel(const float* __restrict__ slabs, int nslabs,
                                                                  long slab_stride, const float* __restrict__ resid,
                                                                  float* __restrict__ h_out,
                                                                  const float* __restrict__ w, bf16* __restrict__ y,
                                                                  long T, int d, float eps, int round_bf16) {
+    // one wave per row and one row per workgroup: the rows are few (decode) and should land on different CUs
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long row = blockIdx.x;
     if (row >= T) return;
     f32x4 hv[VPL];
     float ss = 0.f;
@@ -26,6 +27,7 @@ __global__ __launch_bounds__(256) void slab_resid_rmsnorm_kernel(const float* __
         hv[i] = f32x4{0, 0, 0, 0};
         if (c < d) {
             f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + row * d + c);
+#pragma unroll 8
             for (int z = 1; z < nslabs; ++z) acc += *reinterpret_cast<const f32x4*>(slabs + z * slab_stride + row * d + c);
             if (round_bf16) {
 #pragma unroll
@@ -62,7 +64,8 @@ extern "C" int mgen_slab_resid_rmsnorm(const float* slabs, int nslabs, long slab
     MGEN_REQUIRE(slabs && resid && h_out && nslabs >= 1 && T > 0, "mgen_slab_resid_rmsnorm: bad arguments");
     MGEN_REQUIRE((w == nullptr) == (y == nullptr), "mgen_slab_resid_rmsnorm: w and y go together");
     MGEN_REQUIRE(d > 0 && d % 4 == 0 && d <= 2048, "mgen_slab_resid_rmsnorm: need 0<d<=2048, d%%4==0 (d=%d)", d);
-    const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+    MGEN_REQUIRE(T < (1L << 31), "mgen_slab_resid_rmsnorm: too many rows");
+    const dim3 grid((unsigned)T), block(64);
     if (d <= 512)
         hipLaunchKernelGGL(slab_resid_rmsnorm_kernel<2>, grid, block, 0, stream, slabs, nslabs, slab_stride, resid,
                            h_out, w, (bf16*)y, T, d, eps, round_bf16);
