@@ -34,7 +34,21 @@ struct AttnArgs {
     long sq, sk, sv, so, sdo, sdq, sdk, sdv;  // token strides in elements
     int B, S, H, KVH;
     float scale;
+    int gx, gy, gz;  // logical grid: row blocks, head (pair) index, batch; launched as one dimension
 };
+
+// Logical workgroup coordinates from the 1-D launch index. Hardware deals consecutive workgroups round-robin to the
+// 8 XCDs; the remap gives each XCD a contiguous range of logical ids, so all row blocks of one (batch, head) run on
+// the same XCD at about the same time and share its L2 for the K/V (or Q/dO) tiles they all stream.
+struct Coords { int x, y, z; };
+__device__ __forceinline__ Coords block_coords(const AttnArgs& a) {
+    const int L = xcd_remap(blockIdx.x, a.gx * a.gy * a.gz);
+    Coords c;
+    c.x = L % a.gx;
+    c.y = (L / a.gx) % a.gy;
+    c.z = L / (a.gx * a.gy);
+    return c;
+}
 
 template <int HD> struct Geo {
     static constexpr int KS = HD / 16;                  // MFMA k-steps over the head dimension
@@ -111,12 +125,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qb = gridDim.x - 1 - blockIdx.x;  // heaviest (latest) query blocks first
-    const int b = blockIdx.z;
+    const Coords bid = block_coords(a);
+    const int qb = a.gx - 1 - bid.x;  // heaviest (latest) query blocks first
+    const int b = bid.z;
     const int sub = HD == 128 ? 0 : (wave >> 1);             // which head of the pair (head_dim 64)
     const int wq = HD == 128 ? wave : (wave & 1);            // which 32-query slice of the block
-    const int h = HD == 128 ? blockIdx.y : 2 * blockIdx.y + sub;
-    const int kv_first = HD == 128 ? h / (a.H / a.KVH) : 2 * blockIdx.y;  // first kv head of the tile row
+    const int h = HD == 128 ? bid.y : 2 * bid.y + sub;
+    const int kv_first = HD == 128 ? h / (a.H / a.KVH) : 2 * bid.y;  // first kv head of the tile row
     const int ks0 = 4 * sub, db0 = 2 * sub;                  // this head's k-steps / d-blocks inside the tile row
     const int S = a.S;
     const long tok0 = (long)b * S;
@@ -266,12 +281,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qb = gridDim.x - 1 - blockIdx.x;
-    const int b = blockIdx.z;
+    const Coords bid = block_coords(a);
+    const int qb = a.gx - 1 - bid.x;
+    const int b = bid.z;
     const int sub = HD == 128 ? 0 : (wave >> 1);
     const int wq = HD == 128 ? wave : (wave & 1);
-    const int h = HD == 128 ? blockIdx.y : 2 * blockIdx.y + sub;
-    const int kv_first = HD == 128 ? h / (a.H / a.KVH) : 2 * blockIdx.y;
+    const int h = HD == 128 ? bid.y : 2 * bid.y + sub;
+    const int kv_first = HD == 128 ? h / (a.H / a.KVH) : 2 * bid.y;
     const int ks0 = 4 * sub, db0 = 2 * sub;
     const int S = a.S;
     const long tok0 = (long)b * S;
@@ -361,10 +377,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kb = blockIdx.x, b = blockIdx.z;
+    const Coords bid = block_coords(a);
+    const int kb = bid.x, b = bid.z;
     const int sub = HD == 128 ? 0 : (wave >> 1);
     const int wk = HD == 128 ? wave : (wave & 1);
-    const int kvh = HD == 128 ? blockIdx.y : 2 * blockIdx.y + sub;
+    const int kvh = HD == 128 ? bid.y : 2 * bid.y + sub;
     const int ks0 = 4 * sub, db0 = 2 * sub;
     const int S = a.S;
     const long tok0 = (long)b * S;
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
 
     auto issue = [&](int step, int buf) {
         // first query head of the tile row for this step
-        const int hq0 = HD == 128 ? blockIdx.y * group + step / per_head : 2 * blockIdx.y;
+        const int hq0 = HD == 128 ? bid.y * group + step / per_head : 2 * bid.y;
         const int qt0 = (t_first + step % per_head) * 64;
         char* base = smem + buf * DKV_BUF;
         tile_glds(a.Q + (long)hq0 * HD, a.sq, tok0, qt0, S, base, tid);
@@ -518,10 +535,13 @@ extern "C" int mgen_attn_fwd(const void* q, const void* k, const void* v, void* 
     if (int e = check_common(a, head_dim, "mgen_attn_fwd")) return e;
     MGEN_REQUIRE(so % 4 == 0, "mgen_attn_fwd: output token stride must be a multiple of 4");
     const dim3 block(256);
-    if (head_dim == 128)
-        hipLaunchKernelGGL(attn_fwd_kernel<128>, dim3((S + 127) / 128, H, B), block, 4 * TILE, stream, a);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, dim3((S + 63) / 64, H / 2, B), block, 4 * TILE, stream, a);
+    a.gx = head_dim == 128 ? (S + 127) / 128 : (S + 63) / 64;
+    a.gy = head_dim == 128 ? H : H / 2;
+    a.gz = B;
+    MGEN_REQUIRE((long)a.gx * a.gy * a.gz < (1L << 31), "mgen_attn_fwd: grid too large");
+    const dim3 grid((unsigned)(a.gx * a.gy * a.gz));
+    if (head_dim == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 4 * TILE, stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 4 * TILE, stream, a);
     return mgen_check_launch("mgen_attn_fwd");
 }
 
@@ -549,14 +569,20 @@ extern "C" int mgen_attn_bwd(const void* q, const void* k, const void* v, const 
     long nb = (nrows + rpb - 1) / rpb;
     if (nb > 8192) nb = 8192;
     const dim3 block(256);
+    const int nrb = head_dim == 128 ? (S + 127) / 128 : (S + 63) / 64;   // row blocks
+    MGEN_REQUIRE((long)nrb * H * B < (1L << 31), "mgen_attn_bwd: grid too large");
+    AttnArgs akv = a, aq = a;   // the two kernels walk different logical grids
+    akv.gx = nrb; akv.gy = head_dim == 128 ? KVH : KVH / 2; akv.gz = B;
+    aq.gx = nrb; aq.gy = head_dim == 128 ? H : H / 2; aq.gz = B;
+    const dim3 gkv((unsigned)(akv.gx * akv.gy * akv.gz)), gq((unsigned)(aq.gx * aq.gy * aq.gz));
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)nb), block, 0, stream, a.O, a.dO, so, sdo, delta, B, S, H);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, dim3((S + 127) / 128, KVH, B), block, 2 * DKV_BUF, stream, a);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, dim3((S + 127) / 128, H, B), block, 4 * TILE, stream, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gkv, block, 2 * DKV_BUF, stream, akv);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, block, 4 * TILE, stream, aq);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)nb), block, 0, stream, a.O, a.dO, so, sdo, delta, B, S, H);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3((S + 63) / 64, KVH / 2, B), block, 2 * DKV_BUF, stream, a);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((S + 63) / 64, H / 2, B), block, 4 * TILE, stream, a);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gkv, block, 2 * DKV_BUF, stream, akv);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, block, 4 * TILE, stream, aq);
     }
     return mgen_check_launch("mgen_attn_bwd");
 }
