@@ -116,10 +116,13 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
     // XCD-aware, grouped tile order: 8 row-tiles share the sweep over the column tiles
     const int nwg = g.nbm * g.nbn;
     const int wid = xcd_remap(blockIdx.x, nwg * g.splitk);
-    const int wg = wid / g.splitk;
-    const int kbeg = (wid % g.splitk) * g.kper;
+    // K-slice-major: the output tiles of one K slice are neighbours (same XCD, same time) and share that slice of
+    // both operands in L2; slices of the same output tile meet only in the fp32 atomics / slabs
+    const int wg = wid % nwg;
+    const int kslice = wid / nwg;
+    const int kbeg = kslice * g.kper;
     const int kend = min(g.K, kbeg + g.kper);
-    const long coff = (long)(wid % g.splitk) * g.slab_stride;
+    const long coff = (long)kslice * g.slab_stride;
     constexpr int GROUP = 8;
     const int width = GROUP * g.nbn;
     const int grp = wg / width;
@@ -420,9 +423,13 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     // An accumulating product with few output tiles and a long reduction (weight gradients: K = tokens) is cut
     // along K so that the chip is filled; the slices add their tiles with fp32 atomics.
     const long tiles = (long)g.nbm * g.nbn;
-    if (out_mode == OUT_F32_ACC && tiles < 512) {
-        const int ksteps = (K + BK - 1) / BK;
-        int want = (int)(1024 / tiles);  // 4 workgroups per CU x 256 CUs resident at once: fill them in ONE round
+    const int ksteps_all = (K + BK - 1) / BK;
+    if (out_mode == OUT_F32_ACC && (tiles < 512 || ksteps_all >= 1024)) {
+        const int ksteps = ksteps_all;
+        int want = tiles < 512 ? (int)(1024 / tiles) : 1;  // 4 workgroups per CU x 256 CUs resident: fill them in ONE round
+        // very long reductions are cut as well: workgroups that stream thousands of K steps drift apart and stop
+        // sharing operand rows in L2
+        if (ksteps >= 1024 && ksteps / 512 > want) want = ksteps / 512;
         int maxsplit = ksteps / 8;  // at least 8 K steps (512 reduction indices) per slice
         int sk = want < maxsplit ? want : maxsplit;
         if (sk > 1) {

@@ -489,10 +489,26 @@ class MidiLM(GenerationMixin, nn.Module):
             if with_grad:
                 # dxN[c] = dlogits[c] @ W ; dW += dlogits[c]^T @ xN[c]
                 dl = ops.presplit(logits)
-                ops.gemm_any(dl, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
-                ops.gemm_any(dl, xc, self._lm_grad_tmp, V, d, n, ld, xc.stride(0), d, True, True,
-                             ops.OUT_F32 if first else ops.OUT_F32_ACC)
-                first = False
+                if isinstance(dl, ops.W2):
+                    ops.gemm_any(dl, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
+                else:
+                    # reduction over the whole vocabulary: accumulate in fp32 so that the GEMM may cut it into
+                    # slices (see mgen_gemm_bf16), then round once
+                    acc = torch.zeros(n, d, dtype=torch.float32, device=dev)
+                    ops.gemm(dl, W, acc, n, d, V, ld, W.stride(0), d, False, True, ops.OUT_F32_ACC)
+                    ops.cast(acc, dxN[t0:t0 + n])
+                # the weight-gradient product runs over 8192 tokens per launch: its workgroups stream the whole
+                # reduction range and stay in step (sharing the activation rows in L2) only over a short range
+                if isinstance(dl, ops.W2):
+                    ops.gemm_any(dl, xc, self._lm_grad_tmp, V, d, n, ld, xc.stride(0), d, True, True,
+                                 ops.OUT_F32 if first else ops.OUT_F32_ACC)
+                    first = False
+                else:
+                    for r0 in range(0, n, 8192):
+                        rn = min(8192, n - r0)
+                        ops.gemm(dl[r0:r0 + rn], xc[r0:r0 + rn], self._lm_grad_tmp, V, d, rn, ld, xc.stride(0), d,
+                                 True, True, ops.OUT_F32 if first else ops.OUT_F32_ACC)
+                        first = False
         loss = torch.empty((), dtype=torch.float32, device=dev)
         ops.ce_finalize(row_loss, inv_count, loss)
         return loss, dxN
