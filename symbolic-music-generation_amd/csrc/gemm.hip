@@ -423,13 +423,9 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     // An accumulating product with few output tiles and a long reduction (weight gradients: K = tokens) is cut
     // along K so that the chip is filled; the slices add their tiles with fp32 atomics.
     const long tiles = (long)g.nbm * g.nbn;
-    const int ksteps_all = (K + BK - 1) / BK;
-    if (out_mode == OUT_F32_ACC && (tiles < 512 || ksteps_all >= 1024)) {
-        const int ksteps = ksteps_all;
-        int want = tiles < 512 ? (int)(1024 / tiles) : 1;  // 4 workgroups per CU x 256 CUs resident: fill them in ONE round
-        // very long reductions are cut as well: workgroups that stream thousands of K steps drift apart and stop
-        // sharing operand rows in L2
-        if (ksteps >= 1024 && ksteps / 512 > want) want = ksteps / 512;
+    if (out_mode == OUT_F32_ACC && tiles < 512) {
+        const int ksteps = (K + BK - 1) / BK;
+        int want = (int)(1024 / tiles);  // 4 workgroups per CU x 256 CUs resident at once: fill them in ONE round
         int maxsplit = ksteps / 8;  // at least 8 K steps (512 reduction indices) per slice
         int sk = want < maxsplit ? want : maxsplit;
         if (sk > 1) {

@@ -489,14 +489,7 @@ class MidiLM(GenerationMixin, nn.Module):
             if with_grad:
                 # dxN[c] = dlogits[c] @ W ; dW += dlogits[c]^T @ xN[c]
                 dl = ops.presplit(logits)
-                if isinstance(dl, ops.W2):
-                    ops.gemm_any(dl, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
-                else:
-                    # reduction over the whole vocabulary: accumulate in fp32 so that the GEMM may cut it into
-                    # slices (see mgen_gemm_bf16), then round once
-                    acc = torch.zeros(n, d, dtype=torch.float32, device=dev)
-                    ops.gemm(dl, W, acc, n, d, V, ld, W.stride(0), d, False, True, ops.OUT_F32_ACC)
-                    ops.cast(acc, dxN[t0:t0 + n])
+                ops.gemm_any(dl, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
                 # the weight-gradient product runs over 8192 tokens per launch: its workgroups stream the whole
                 # reduction range and stay in step (sharing the activation rows in L2) only over a short range
                 if isinstance(dl, ops.W2):
