@@ -162,7 +162,7 @@ def main():
                 e0.record()
                 orig(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, *rest, **kw)
                 e1.record()
-                recs.append((2.0 * M * N * K, e0, e1))
+                recs.append((2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N)))
             else:
                 orig(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, *rest, **kw)
 
@@ -173,9 +173,20 @@ def main():
         fl = sum(r[0] for r in recs)
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         achieved = fl / (ms * 1e-3) / 1e12
+        # HBM traffic per launch of this kernel cannot be counted from inside the process: it comes from the committed
+        # PMC passes of this same command (profiles/r01_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs,
+        # FETCH doubled per the gfx950 note), valid for the default workload only
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if (B, S) == (32, 2048) and os.path.exists(pmc):
+            with open(pmc) as fh:
+                traffic = json.load(fh).get("gemm_fwd_bf16_avg_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<TA=0,TB=0,OUT_BF16> (QKV, gate-up, lm_head forward)",
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json); algorithmic: "
+                                    "2*(M*K + N*K + M*N) bytes",
+                    "algorithmic_bytes_per_launch": round(sum(r[3] for r in recs) / len(recs)),
                     "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 4),
                     "flops_per_launch_avg": fl / len(recs)}
 
