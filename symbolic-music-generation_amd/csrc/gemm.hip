@@ -107,10 +107,14 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int o0, int ks, in
 
 // GLDS = true: single 32 KiB LDS image filled by LDS-DMA, two barriers per K step, up to 4 workgroups per CU cover
 // each other's load latency. GLDS = false: register-staged, zero-filling variant for K not a multiple of 64.
-template <bool TA, bool TB, int MODE, bool GLDS>
-__global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
+// NJ = 32-column MFMA tiles per wave: 2 -> 128-wide workgroup tile (wave 64x64), 4 -> 256-wide (wave 64x128, GLDS
+// only). A k-step of a 64x64 wave tile reads 4 fragments from LDS for 4 MFMAs, which keeps the CU's LDS port as busy
+// as its matrix cores; the 64x128 wave tile reads 6 fragments for 8 MFMAs.
+template <bool TA, bool TB, int MODE, bool GLDS, int NJ>
+__global__ __launch_bounds__(256, GLDS ? (NJ == 4 ? 2 : 3) : 2) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // buffer b: A tile at smem + b*2*TILE_BYTES, B tile right behind it
+    // buffer b: A tile at smem + b*2*TILE_BYTES, B tile right behind it (GLDS: A tile, then NJ/2 B tiles of 128 columns)
+    constexpr int BNW = 64 * NJ;   // workgroup tile width
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware, grouped tile order: 8 row-tiles share the sweep over the column tiles
@@ -130,35 +134,40 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
     const int gsz = min(g.nbm - first_m, GROUP);
     const int tm = first_m + (wg % width) % gsz;
     const int tn = (wg % width) / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = tm * BM, n0 = tn * BNW;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * (32 * NJ);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
     if (GLDS) {
+        // the wave's B columns [wn, wn + 32*NJ) lie inside one 128-column B image
+        const char* btile = smem + TILE_BYTES * (1 + (wn >> 7));
+        const int bcol = wn & 127;
         for (int kt = 0; kt < nk; ++kt) {
             glds_tile<TA>(g.A, g.lda, m0, kbeg + kt * BK, g.M, smem, tid);
-            glds_tile<TB>(g.B, g.ldb, n0, kbeg + kt * BK, g.N, smem + TILE_BYTES, tid);
+#pragma unroll
+            for (int hb = 0; hb < NJ / 2; ++hb)
+                glds_tile<TB>(g.B, g.ldb, n0 + 128 * hb, kbeg + kt * BK, g.N, smem + TILE_BYTES * (1 + hb), tid);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 fa[2], fb[2];
+                bf16x8 fa[2], fb[NJ];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) fa[i] = load_frag<TA>(smem, wm + 32 * i, ks, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = load_frag<TB>(smem + TILE_BYTES, wn + 32 * j, ks, lane);
+                for (int j = 0; j < NJ; ++j) fb[j] = load_frag<TB>(btile, bcol + 32 * j, ks, lane);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = (MODE == OUT_F32_ATOMIC) ? mfma32(fa[i], fb[j], acc[i][j])
                                                              : mfma32(fb[j], fa[i], acc[i][j]);
             }
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + wn + 32 * j + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
         // the lane holds, per tile, columns 8*g4 + 4*h + e of the tile: add the bias to the fp32 accumulators
         // (alpha is 1 whenever a bias is given)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int n = n0 + wn + 32 * j + 8 * g4 + 4 * h;
@@ -244,37 +253,42 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
         // bf16 output through LDS: the wave parks its 64x64 sub-tile in its own 8 KiB of the (now idle) staging
         // area as [64 rows][128 bytes] with the 16-byte chunks XOR-swizzled by row, then writes whole 128-byte row
         // segments with 16 bytes per lane (8 store instructions per lane instead of 32 scattered 8-byte ones).
+        // (a 64x128 wave tile goes through the same 8 KiB in two 64-column halves.)
         char* st = smem + wave * 8192;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int row = 32 * i + (lane & 31);
-                    const int ch = 4 * j + g4;
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][j][4 * g4 + e] * g.alpha);
-                    *reinterpret_cast<bf16x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4) + 8 * h) = o;
-                }
-        // same wave wrote and reads: no workgroup barrier needed, only the LDS counter
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         bf16* C = reinterpret_cast<bf16*>(g.C);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3), ch = lane & 7;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4));
-            const int m = m0 + wm + row, n = n0 + wn + ch * 8;
-            if (m < g.M) {
-                bf16* c = C + (long)m * g.ldc + n;
-                if (n + 7 < g.N) {
-                    *reinterpret_cast<u32x4*>(c) = v;
-                } else {
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+        for (int half = 0; half < NJ / 2; ++half) {
+            if (half) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous half has been read out
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (n + e < g.N) c[e] = b[e];
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int row = 32 * i + (lane & 31);
+                        const int ch = 4 * j + g4;
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][2 * half + j][4 * g4 + e] * g.alpha);
+                        *reinterpret_cast<bf16x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4) + 8 * h) = o;
+                    }
+            // same wave wrote and reads: no workgroup barrier needed, only the LDS counter
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4));
+                const int m = m0 + wm + row, n = n0 + wn + 64 * half + ch * 8;
+                if (m < g.M && n < g.N) {
+                    bf16* c = C + (long)m * g.ldc + n;
+                    if (n + 7 < g.N) {
+                        *reinterpret_cast<u32x4*>(c) = v;
+                    } else {
+                        const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (n + e < g.N) c[e] = b[e];
+                    }
                 }
             }
         }
@@ -287,8 +301,9 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
         char* st = smem + wave * 8192;
         float* C = reinterpret_cast<float*>(g.C) + coff;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int pass = 0; pass < NJ; ++pass) {   // (row half i, 64-column half) of the wave tile
+            const int i = pass & 1, half = pass >> 1;
+            if (pass) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
                     const int ch = 8 * j + 2 * g4 + h;
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g4 + e] * g.alpha;
+                    for (int e = 0; e < 4; ++e) o[e] = acc[i][2 * half + j][4 * g4 + e] * g.alpha;
                     *reinterpret_cast<f32x4*>(st + row * 256 + ((ch ^ (row & 15)) << 4)) = o;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
             for (int it = 0; it < 8; ++it) {
                 const int row = it * 4 + (lane >> 4), ch = lane & 15;
                 f32x4 v = *reinterpret_cast<const f32x4*>(st + row * 256 + ((ch ^ (row & 15)) << 4));
-                const int m = m0 + wm + 32 * i + row, n = n0 + wn + ch * 4;
+                const int m = m0 + wm + 32 * i + row, n = n0 + wn + 64 * half + ch * 4;
                 if (m < g.M && n < g.N) {
                     float* c = C + (long)m * g.ldc + n;
                     if (MODE == OUT_F32_RESID_BF16ROUND || MODE == OUT_F32_RESID) {
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
         const int m = m0 + wm + 32 * i + (lane & 31);
         if (m >= g.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int n = n0 + wn + 32 * j + 8 * g4 + 4 * h;
@@ -370,19 +385,23 @@ __global__ __launch_bounds__(256, GLDS ? 3 : 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
-template <bool TA, bool TB, bool GLDS>
+template <bool TA, bool TB, bool GLDS, int NJ>
 int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
     const dim3 grid(g.nbm * g.nbn * g.splitk), block(256);
-    const size_t lds = (GLDS ? 2 : 4) * TILE_BYTES;
+    const size_t lds = (GLDS ? 1 + NJ / 2 : 4) * TILE_BYTES;
     switch (mode) {
-        case OUT_BF16: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_BF16, GLDS>), grid, block, lds, s, g); break;
-        case OUT_F32: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32, GLDS>), grid, block, lds, s, g); break;
-        case OUT_F32_ACC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ACC, GLDS>), grid, block, lds, s, g); break;
+        case OUT_BF16: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_BF16, GLDS, NJ>), grid, block, lds, s, g); break;
+        case OUT_F32: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32, GLDS, NJ>), grid, block, lds, s, g); break;
+        case OUT_F32_ACC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ACC, GLDS, NJ>), grid, block, lds, s, g); break;
         case OUT_F32_RESID_BF16ROUND:
-            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID_BF16ROUND, GLDS>), grid, block, lds, s, g);
+            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID_BF16ROUND, GLDS, NJ>), grid, block, lds, s, g);
             break;
-        case OUT_F32_RESID: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID, GLDS>), grid, block, lds, s, g); break;
-        case OUT_F32_ATOMIC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ATOMIC, GLDS>), grid, block, lds, s, g); break;
+        case OUT_F32_RESID:
+            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID, GLDS, NJ>), grid, block, lds, s, g);
+            break;
+        case OUT_F32_ATOMIC:
+            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ATOMIC, GLDS, NJ>), grid, block, lds, s, g);
+            break;
         default: mgen_set_error("mgen_gemm_bf16: unknown out_mode %d", mode); return MGEN_EINVAL;
     }
     return mgen_check_launch("mgen_gemm_bf16");
@@ -417,6 +436,15 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.nbm = (M + BM - 1) / BM; g.nbn = (N + BN - 1) / BN;
     MGEN_REQUIRE(out_mode >= 0 && out_mode <= OUT_F32_RESID, "mgen_gemm_bf16: unknown out_mode %d", out_mode);
+    const bool glds = (K % BK) == 0;
+    // 256-wide workgroup tiles (64x128 per wave) when they still give every CU at least two workgroups
+    static const int wide_env = [] { const char* e = getenv("MGEN_GEMM_WIDE"); return e ? atoi(e) : -1; }();
+    // (measured: +5..13 % on the layer products and the lm_head weight gradient; the short-K, very wide lm_head
+    // forward is store-bound per tile and stays on 128-wide tiles)
+    bool wide = glds && slabs <= 1 && N >= 256 && (long)g.nbm * ((N + 255) / 256) >= 512 &&
+                !(K <= 512 && N >= 65536);
+    if (wide_env == 0) wide = false;
+    if (wide) g.nbn = (N + 255) / 256;
     g.splitk = 1;
     g.slab_stride = 0;
     g.kper = ((K + BK - 1) / BK) * BK;
@@ -446,9 +474,10 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
         g.slab_stride = slab_stride;
     }
     MGEN_REQUIRE(tiles * g.splitk < (1L << 31), "mgen_gemm_bf16: grid too large");
-    const bool glds = (K % BK) == 0;
-#define MGEN_GEMM_GO(TA_, TB_) \
-    return glds ? launch_mode<TA_, TB_, true>(g, out_mode, stream) : launch_mode<TA_, TB_, false>(g, out_mode, stream)
+#define MGEN_GEMM_GO(TA_, TB_)                                                          \
+    return wide ? launch_mode<TA_, TB_, true, 4>(g, out_mode, stream)                   \
+                : (glds ? launch_mode<TA_, TB_, true, 2>(g, out_mode, stream)           \
+                        : launch_mode<TA_, TB_, false, 2>(g, out_mode, stream))
     if (!transA && !transB) MGEN_GEMM_GO(false, false);
     if (!transA && transB) MGEN_GEMM_GO(false, true);
     if (transA && !transB) MGEN_GEMM_GO(true, false);
