@@ -178,6 +178,20 @@ int mgen_attn_f32_bwd(const float* q, const float* k, const float* v, const floa
                       long sdo, long sdq, long sdk, long sdv, int B, int S, int H, int KVH, int D, float scale,
                       mgen_stream_t stream);
 
+/* ---- batch assembly on the device ---------------------------------------------------------------------------------
+ * Token batches: flat = the B examples back to back, offsets[B+1]; outputs [B][S] int64 right-padded with pad_id.
+ * mask_pads=1, prompt_len=null: miditok DataCollator(pad, copy_inputs_as_labels=True) (reference src/train.py:33-34):
+ * labels = ids with -100 on padding, attention mask 1 on real tokens. mask_pads=0 with prompt_len[B]: the melody
+ * collate_fn (reference src/train_aria.py:118-145): labels = ids with -100 on the first prompt_len[b] positions,
+ * padding not masked. mask / labels may be null. */
+int mgen_collate_tokens(const long* flat, const long* offsets, const int* prompt_len, long* ids, long* mask,
+                        long* labels, int B, int S, long pad_id, int mask_pads, mgen_stream_t stream);
+/* 4-D position batches, MidiDataset4D._create_chunks (reference src/train_model_new.py:114-158): rows fp32 [total][4];
+ * batch entry b takes chunk chunk_ids[b] of S rows, padded with [last start, 0, 2, 0]; labels = next row with the
+ * start difference in column 0 (last label: the last row, difference 0), -100 on the padded tail. */
+int mgen_collate_pos4d(const float* rows, long total, const long* chunk_ids, float* pos, float* labels, long* mask,
+                       long* ids, int B, int S, mgen_stream_t stream);
+
 /* dtype conversion: kind 0 fp32 -> bf16, 1 bf16 -> fp32. */
 int mgen_cast(const void* in, void* out, long n, int kind, mgen_stream_t stream);
 

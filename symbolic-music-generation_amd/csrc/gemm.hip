@@ -5,12 +5,15 @@
 // backward): forward x*W^T (A k-contiguous, B k-contiguous), dgrad dY*W (B stored [K][N]), wgrad dY^T*X (both
 // operands stored with the reduction index as the row index).
 //
-// Tiling: 256 threads = 4 waves, block tile 128x128, K step 64, each wave a 64x64 sub-tile as 2x2
-// v_mfma_f32_32x32x16_bf16 tiles. Operand tiles are staged global -> registers -> LDS (16-byte vectors, zero
-// filled out of range) into two LDS buffers, one barrier per K step; the next tile's global loads are issued
-// before the MFMAs of the current one. An operand whose reduction index is contiguous in memory lives in LDS as
-// [128 rows][64 k] (row reads); one whose reduction index is the row index lives as [64 k][128 cols] and is read
-// with the transposing LDS read, so no transposed copy of activations or weights is ever made in HBM.
+// Tiling: 256 threads = 4 waves, K step 64, v_mfma_f32_32x32x16_bf16. Workgroup tile 128x256 (each wave 64x128)
+// when the product has enough row tiles, else 128x128 (each wave 64x64). When K is a multiple of 64 the operand
+// tiles go global -> LDS by LDS-DMA into ONE stage (48 or 32 KiB), with 2-4 workgroups per CU covering each other's
+// load latency (a second stage per workgroup costs more in occupancy than it hides: measured); otherwise a
+// register-staged, zero-filling, double-buffered variant is used. An operand whose reduction index is contiguous
+// in memory lives in LDS as [128 rows][64 k] (row reads); one whose reduction index is the row index lives as
+// [64 k][128 cols] and is read with the transposing LDS read, so no transposed copy of activations or weights is
+// ever made in HBM. Workgroups are numbered so that each XCD (own L2) gets a contiguous range of tiles, grouped 8
+// row tiles at a time; split-K slices are numbered slice-major.
 #include "common.h"
 
 namespace {

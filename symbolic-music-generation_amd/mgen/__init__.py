@@ -6,3 +6,4 @@ from .config import LMConfig, default_decoder, aria_style_llama, pos4d_decoder, 
 from .model import MidiLM, CausalLMOutput  # noqa: F401
 from .gpt2 import MidiGPT2LM  # noqa: F401
 from .optim import FusedAdamW, get_optim  # noqa: F401
+from .collate import DataCollator, MidiDataset4D  # noqa: F401

@@ -45,6 +45,8 @@ SIGNATURES = {
     "mgen_swiglu_f32_bwd": [P, P, P, L, I, P],
     "mgen_attn_f32_fwd": [P, P, P, P, P, L, L, L, L, I, I, I, I, I, F, P],
     "mgen_attn_f32_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, P],
+    "mgen_collate_tokens": [P, P, P, P, P, P, I, I, L, I, P],
+    "mgen_collate_pos4d": [P, L, P, P, P, P, P, I, I, P],
     "mgen_cast": [P, P, L, I, P],
     "mgen_ce_count": [P, L, I, L, P, P, P],
     "mgen_ce_fwd_bwd": [P, P, L, L, I, L, I, L, P, F, P, P, I, I, P],

@@ -273,6 +273,22 @@ def pos4d_next(pred, ld_pred, prev, ld_prev, nxt, ld_next, B):
     call("mgen_pos4d_next", pred, ld_pred, prev, ld_prev, nxt, ld_next, B, _stream())
 
 
+def collate_tokens(flat, offsets, prompt_len, ids, mask, labels, pad_id, mask_pads):
+    """flat int64 [sum len], offsets int64 [B+1], prompt_len int32 [B] or None; ids/mask/labels int64 [B, S]."""
+    _need_gpu(flat, offsets, prompt_len, ids, mask, labels)
+    B, S = ids.shape
+    call("mgen_collate_tokens", _p(flat), _p(offsets), _p(prompt_len), _p(ids), _p(mask), _p(labels), B, S,
+         int(pad_id), int(bool(mask_pads)), _stream())
+
+
+def collate_pos4d(rows, chunk_ids, pos, labels, mask, ids):
+    """rows fp32 [total, 4], chunk_ids int64 [B]; pos/labels fp32 [B, S, 4]; mask/ids int64 [B, S] or None."""
+    _need_gpu(rows, chunk_ids, pos, labels, mask, ids)
+    B, S = pos.shape[0], pos.shape[1]
+    call("mgen_collate_pos4d", _p(rows), rows.shape[0], _p(chunk_ids), _p(pos), _p(labels), _p(mask), _p(ids), B, S,
+         _stream())
+
+
 def attn_fwd(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, D, scale, f32=False):
     """q/k/v/out are raw device pointers (ints) of token-major views (bf16, or fp32 with f32=True); strides in
     elements."""

@@ -488,8 +488,65 @@ def gpt2_case(name="tiny_gpt2", B=2, S=128):
           "last", losses[-1])
 
 
+def load_reference_collate():
+    """Pull the batch-assembly functions out of the reference's training scripts without importing those scripts
+    (their top-level imports need miditok / symusic / lightning, absent here): the function definitions are compiled
+    from the parsed source with only `torch` in scope."""
+    import ast
+    ns = {"torch": torch}
+    tree = ast.parse(open("/root/reference/src/train_aria.py").read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("collate_fn", "style_collate_fn")]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "train_aria.py", "exec"), ns)
+    tree = ast.parse(open("/root/reference/src/train_model_new.py").read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "custom_collate_fn"]
+    for n in tree.body:
+        if isinstance(n, ast.ClassDef) and n.name == "MidiDataset4D":
+            keep += [m for m in n.body if isinstance(m, ast.FunctionDef) and m.name == "_create_chunks"]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "train_model_new.py", "exec"), ns)
+    return ns["collate_fn"], ns["style_collate_fn"], ns["_create_chunks"], ns["custom_collate_fn"]
+
+
+def collate_case(name="collate"):
+    """Ragged token batches through the reference's two in-tree collate functions, and a concatenated note-row
+    sequence through MidiDataset4D._create_chunks + custom_collate_fn (last chunk short)."""
+    import contextlib
+    import io
+    import types
+    melody_fn, style_fn, create_chunks, stack_fn = load_reference_collate()
+    gen = torch.Generator().manual_seed(99)
+    lens = [137, 512, 1, 300, 511, 64]
+    seqs = [torch.randint(3, 17000, (n,), generator=gen).tolist() for n in lens]
+    mel = [40, 512, 0, 299, 100, 64]
+    pad_id = 2
+    out = {"tok_flat": np.concatenate([np.asarray(s, np.int64) for s in seqs]),
+           "tok_offsets": np.cumsum([0] + lens).astype(np.int64), "tok_melody": np.asarray(mel, np.int32),
+           "tok_pad_id": pad_id}
+    o = melody_fn([{"input_ids": s, "melody_length": m} for s, m in zip(seqs, mel)], pad_id)
+    out["melody_input_ids"], out["melody_labels"] = o["input_ids"].numpy(), o["labels"].numpy()
+    o = style_fn([{"input_ids": s} for s in seqs], pad_id)
+    out["style_input_ids"], out["style_labels"] = o["input_ids"].numpy(), o["labels"].numpy()
+
+    S = 64
+    pos, _, _ = synth_notes(gen, 1, 5 * S - 23)
+    rows = pos[0]
+    ds = types.SimpleNamespace(max_seq_len=S, chunks=[])
+    with contextlib.redirect_stdout(io.StringIO()):   # the method prints two lines per chunk
+        create_chunks(ds, rows)
+    assert len(ds.chunks) == 5
+    order = [4, 0, 2, 2, 1, 3]
+    o = stack_fn([ds.chunks[c] for c in order])
+    out["p4_rows"], out["p4_S"], out["p4_chunk_ids"] = rows.numpy(), S, np.asarray(order, np.int64)
+    for k in ("input_ids", "attention_mask", "labels", "position_tensors"):
+        out["p4_" + k] = o[k].numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: getattr(v, "shape", v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     print("transformers", transformers.__version__, "torch", torch.__version__)
+    if "--collate-only" in sys.argv:
+        collate_case()
+        sys.exit(0)
     if "--pos4d-only" in sys.argv:
         pos4d_case()
         sys.exit(0)
@@ -503,5 +560,6 @@ if __name__ == "__main__":
                         num_attention_heads=4, num_key_value_heads=4, head_dim=64, rms_norm_eps=1e-6,
                         rope_theta=10000.0, tie_word_embeddings=False, qk_norm=False)
     tiny_case("tiny_llama", tiny_l, hf_llama, extra_keys=("lm_head.weight",))
+    collate_case()
     if "--full" in sys.argv:
         full_dq_case()
