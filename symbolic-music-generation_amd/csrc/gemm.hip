@@ -9,7 +9,8 @@
 // when the product has enough row tiles, else 128x128 (each wave 64x64). When K is a multiple of 64 the operand
 // tiles go global -> LDS by LDS-DMA into ONE stage (48 or 32 KiB), with 2-4 workgroups per CU covering each other's
 // load latency (a second stage per workgroup costs more in occupancy than it hides: measured); otherwise a
-// register-staged, zero-filling, double-buffered variant is used. An operand whose reduction index is contiguous
+// register-staged, zero-filling, double-buffered variant is used. Wide products (N >= 1024) with a tile for every CU run on 256x256 tiles with
+// 8 waves and two 64 KiB LDS-DMA stages, one workgroup per CU. An operand whose reduction index is contiguous
 // in memory lives in LDS as [128 rows][64 k] (row reads); one whose reduction index is the row index lives as
 // [64 k][128 cols] and is read with the transposing LDS read, so no transposed copy of activations or weights is
 // ever made in HBM. Workgroups are numbered so that each XCD (own L2) gets a contiguous range of tiles, grouped 8
@@ -77,13 +78,14 @@ __device__ __forceinline__ void store_tile(const u32x4 (&st)[4], char* lds, int 
 // ---- global -> LDS directly (LDS-DMA, 16 bytes per lane): a wave instruction fills one contiguous 1 KiB piece of
 // the tile image, so the XOR swizzle of the image is applied to each lane's SOURCE address. No zero fill: used when
 // K is a multiple of the K step; rows/columns beyond the matrix edge are clamped (they feed outputs never stored).
-template <bool MC>
+template <bool MC, int NW = 4>
 __device__ __forceinline__ void glds_tile(const bf16* __restrict__ P, long ld, int row0, int k0, int nrows,
                                           char* lds_tile, int tid) {
     const int wave = tid >> 6, l = tid & 63;
+    constexpr int PPW = 16 / NW;   // 1 KiB pieces per wave
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int piece = wave * 4 + j;
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;
         const bf16* src;
         if (!MC) {
             const int row = piece * 8 + (l >> 3);
@@ -113,11 +115,17 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int o0, int ks, in
 // NJ = 32-column MFMA tiles per wave: 2 -> 128-wide workgroup tile (wave 64x64), 4 -> 256-wide (wave 64x128, GLDS
 // only). A k-step of a 64x64 wave tile reads 4 fragments from LDS for 4 MFMAs, which keeps the CU's LDS port as busy
 // as its matrix cores; the 64x128 wave tile reads 6 fragments for 8 MFMAs.
-template <bool TA, bool TB, int MODE, bool GLDS, int NJ>
-__global__ __launch_bounds__(256, GLDS ? (NJ == 4 ? 2 : 3) : 2) void gemm_kernel(GemmArgs g) {
+// WM = 128-row A images per workgroup: 1 -> 4 waves; 2 -> 8 waves on a 256x256 tile (NJ = 4, GLDS), two 64 KiB LDS
+// stages, one workgroup per CU: the LDS-DMA of K step kt+1 is issued before the MFMAs of step kt and one barrier per
+// step both publishes a stage and frees the other. The 256x256 tile moves half the operand bytes per flop of the
+// 128x128 one: what bounds the smaller tiles is the rate at which tiles can be brought from L2 into LDS.
+template <bool TA, bool TB, int MODE, bool GLDS, int NJ, int WM = 1>
+__global__ __launch_bounds__(256 * WM, WM == 2 ? 2 : (GLDS ? (NJ == 4 ? 2 : 3) : 2)) void gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // buffer b: A tile at smem + b*2*TILE_BYTES, B tile right behind it (GLDS: A tile, then NJ/2 B tiles of 128 columns)
     constexpr int BNW = 64 * NJ;   // workgroup tile width
+    constexpr int BMW = BM * WM;   // workgroup tile height
+    static_assert(WM == 1 || (GLDS && NJ == 4), "256-row tiles: LDS-DMA variant with 256 columns only");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware, grouped tile order: 8 row-tiles share the sweep over the column tiles
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256, GLDS ? (NJ == 4 ? 2 : 3) : 2) void gemm_kernel
     const int gsz = min(g.nbm - first_m, GROUP);
     const int tm = first_m + (wg % width) % gsz;
     const int tn = (wg % width) / gsz;
-    const int m0 = tm * BM, n0 = tn * BNW;
+    const int m0 = tm * BMW, n0 = tn * BNW;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * (32 * NJ);
 
     f32x16 acc[2][NJ];
@@ -149,7 +157,42 @@ __global__ __launch_bounds__(256, GLDS ? (NJ == 4 ? 2 : 3) : 2) void gemm_kernel
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    if (GLDS) {
+    if (GLDS && WM == 2) {
+        constexpr int STAGE = 4 * TILE_BYTES;   // [A rows 0..127][A rows 128..255][B cols 0..127][B cols 128..255]
+        auto issue = [&](int kt, char* st) {
+            const int k0 = kbeg + kt * BK;
+            glds_tile<TA, 8>(g.A, g.lda, m0, k0, g.M, st, tid);
+            glds_tile<TA, 8>(g.A, g.lda, m0 + 128, k0, g.M, st + TILE_BYTES, tid);
+            glds_tile<TB, 8>(g.B, g.ldb, n0, k0, g.N, st + 2 * TILE_BYTES, tid);
+            glds_tile<TB, 8>(g.B, g.ldb, n0 + 128, k0, g.N, st + 3 * TILE_BYTES, tid);
+        };
+        issue(0, smem);
+        const int aoff = TILE_BYTES * (wm >> 7), arow = wm & 127;
+        const int boff = TILE_BYTES * (2 + (wn >> 7));
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* cur = smem + (kt & 1) * STAGE;
+            // only the loads of step kt are outstanding here; past the barrier every wave has also finished the
+            // MFMAs of step kt-1, so the other stage may be overwritten
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) issue(kt + 1, smem + ((kt + 1) & 1) * STAGE);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fa[2], fb[NJ];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = load_frag<TA>(cur + aoff, arow + 32 * i, ks, lane);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j] = load_frag<TB>(cur + boff, 32 * j, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = (MODE == OUT_F32_ATOMIC) ? mfma32(fa[i], fb[j], acc[i][j])
+                                                             : mfma32(fb[j], fa[i], acc[i][j]);
+            }
+        }
+        __syncthreads();   // the epilogues reuse the staging memory
+    } else if (GLDS) {
         // the wave's B columns [wn, wn + 32*NJ) lie inside one 128-column B image
         const char* btile = smem + TILE_BYTES * (1 + (wn >> 7));
         const int bcol = wn & 127;
@@ -388,26 +431,41 @@ __global__ __launch_bounds__(256, GLDS ? (NJ == 4 ? 2 : 3) : 2) void gemm_kernel
     }
 }
 
-template <bool TA, bool TB, bool GLDS, int NJ>
+template <bool TA, bool TB, int MODE, bool GLDS, int NJ, int WM>
+int launch_one(const GemmArgs& g, hipStream_t s) {
+    const dim3 grid(g.nbm * g.nbn * g.splitk), block(256 * WM);
+    const size_t lds = (WM == 2 ? 8 : (GLDS ? 1 + NJ / 2 : 4)) * TILE_BYTES;
+    if (lds > 65536) {
+        // more than the default 64 KiB of dynamic LDS has to be asked for, once per kernel and device
+        static bool asked[16] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+        if (!asked[dev]) {
+            const hipError_t e = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&gemm_kernel<TA, TB, MODE, GLDS, NJ, WM>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) {
+                mgen_set_error("mgen_gemm_bf16: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+                return MGEN_ELAUNCH;
+            }
+            asked[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_kernel<TA, TB, MODE, GLDS, NJ, WM>), grid, block, lds, s, g);
+    return mgen_check_launch("mgen_gemm_bf16");
+}
+
+template <bool TA, bool TB, bool GLDS, int NJ, int WM = 1>
 int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
-    const dim3 grid(g.nbm * g.nbn * g.splitk), block(256);
-    const size_t lds = (GLDS ? 1 + NJ / 2 : 4) * TILE_BYTES;
     switch (mode) {
-        case OUT_BF16: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_BF16, GLDS, NJ>), grid, block, lds, s, g); break;
-        case OUT_F32: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32, GLDS, NJ>), grid, block, lds, s, g); break;
-        case OUT_F32_ACC: hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ACC, GLDS, NJ>), grid, block, lds, s, g); break;
-        case OUT_F32_RESID_BF16ROUND:
-            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID_BF16ROUND, GLDS, NJ>), grid, block, lds, s, g);
-            break;
-        case OUT_F32_RESID:
-            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_RESID, GLDS, NJ>), grid, block, lds, s, g);
-            break;
-        case OUT_F32_ATOMIC:
-            hipLaunchKernelGGL((gemm_kernel<TA, TB, OUT_F32_ATOMIC, GLDS, NJ>), grid, block, lds, s, g);
-            break;
+        case OUT_BF16: return launch_one<TA, TB, OUT_BF16, GLDS, NJ, WM>(g, s);
+        case OUT_F32: return launch_one<TA, TB, OUT_F32, GLDS, NJ, WM>(g, s);
+        case OUT_F32_ACC: return launch_one<TA, TB, OUT_F32_ACC, GLDS, NJ, WM>(g, s);
+        case OUT_F32_RESID_BF16ROUND: return launch_one<TA, TB, OUT_F32_RESID_BF16ROUND, GLDS, NJ, WM>(g, s);
+        case OUT_F32_RESID: return launch_one<TA, TB, OUT_F32_RESID, GLDS, NJ, WM>(g, s);
+        case OUT_F32_ATOMIC: return launch_one<TA, TB, OUT_F32_ATOMIC, GLDS, NJ, WM>(g, s);
         default: mgen_set_error("mgen_gemm_bf16: unknown out_mode %d", mode); return MGEN_EINVAL;
     }
-    return mgen_check_launch("mgen_gemm_bf16");
 }
 
 }  // namespace
@@ -447,7 +505,15 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     bool wide = glds && slabs <= 1 && N >= 256 && (long)g.nbm * ((N + 255) / 256) >= 512 &&
                 !(K <= 512 && N >= 65536);
     if (wide_env == 0) wide = false;
-    if (wide) g.nbn = (N + 255) / 256;
+    // 256x256 tiles, one workgroup per CU, for products with at least four column tiles and a tile for every CU
+    // (MGEN_GEMM_WIDE=1: never). Measured against the 128x256 tiles: +12 % on 8192^3, +3..6 % on the decoder's
+    // N >= 1024 products, -5..10 % on its N = 512 ones (two tile columns leave no second workgroup per CU to
+    // cover the first K step and the epilogue).
+    const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const bool big = glds && slabs <= 1 && wide_env != 0 && wide_env != 1 && tiles256 >= 256 && N >= 1024 &&
+                     (out_mode != OUT_F32_ACC || tiles256 >= 512);
+    if (big) { wide = false; g.nbm = (M + 255) / 256; }
+    if (wide || big) g.nbn = (N + 255) / 256;
     g.splitk = 1;
     g.slab_stride = 0;
     g.kper = ((K + BK - 1) / BK) * BK;
@@ -478,12 +544,13 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     }
     MGEN_REQUIRE(tiles * g.splitk < (1L << 31), "mgen_gemm_bf16: grid too large");
 #define MGEN_GEMM_GO(TA_, TB_)                                                          \
+    if (big) return launch_mode<TA_, TB_, true, 4, 2>(g, out_mode, stream);             \
     return wide ? launch_mode<TA_, TB_, true, 4>(g, out_mode, stream)                   \
                 : (glds ? launch_mode<TA_, TB_, true, 2>(g, out_mode, stream)           \
                         : launch_mode<TA_, TB_, false, 2>(g, out_mode, stream))
-    if (!transA && !transB) MGEN_GEMM_GO(false, false);
-    if (!transA && transB) MGEN_GEMM_GO(false, true);
-    if (transA && !transB) MGEN_GEMM_GO(true, false);
+    if (!transA && !transB) { MGEN_GEMM_GO(false, false); }
+    if (!transA && transB) { MGEN_GEMM_GO(false, true); }
+    if (transA && !transB) { MGEN_GEMM_GO(true, false); }
     MGEN_GEMM_GO(true, true);
 #undef MGEN_GEMM_GO
 }

@@ -35,7 +35,10 @@ def ops():
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 200, 136), (1000, 72, 1096),
                                    # enough row tiles for the 256-wide workgroup tiles (64x128 per wave), one with a
                                    # ragged last column tile and a ragged last row tile
-                                   (16384, 1024, 128), (32700, 600, 192)])
+                                   (16384, 1024, 128), (32700, 600, 192),
+                                   # 256x256 workgroup tiles (8 waves, double-buffered), accumulate epilogue included,
+                                   # a single K step
+                                   (33000, 1096, 64), (16500, 2040, 320)])
 def test_gemm_layouts(ops, ta, tb, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = bf(torch.randn(M, K, generator=g))

@@ -20,9 +20,12 @@ shapes = [  # name, M, N, K, ta, tb, mode
     ("square 4096", 4096, 4096, 4096, 0, 0, ops.OUT_BF16), ("square 8192", 8192, 8192, 8192, 0, 0, ops.OUT_BF16),
 ]
 tot_t = 0.0
+if len(sys.argv) > 1:   # keep the shapes whose name contains one of the arguments
+    shapes = [s for s in shapes if any(a in s[0] for a in sys.argv[1:])]
 for name, M, N, K, ta, tb, mode in shapes:
-    a = (torch.randn((K, M) if ta else (M, K), device=dev) * 0.5).to(torch.bfloat16)
-    b = (torch.randn((K, N) if tb else (N, K), device=dev) * 0.5).to(torch.bfloat16)
+    PAD = int(os.environ.get("BENCH_LD_PAD", "0"))   # extra elements per operand row (leading-dimension experiment)
+    a = (torch.randn(((K, M + PAD) if ta else (M, K + PAD)), device=dev) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(((K, N + PAD) if tb else (N, K + PAD)), device=dev) * 0.5).to(torch.bfloat16)
     c = torch.zeros(M, N, dtype=torch.bfloat16 if mode == ops.OUT_BF16 else torch.float32, device=dev)
     r = torch.zeros(M, N, dtype=torch.float32, device=dev) if mode == ops.OUT_F32_RESID_BF16ROUND else None
     def run():

@@ -1,0 +1,57 @@
+"""Decode-only kernel breakdown. Two modes:
+
+  python tools/profile_decode.py run [streams] [prompt] [new_tokens]
+      prefill + decode of the default decoder (run it under `rocprofv3 --kernel-trace --output-format csv`)
+  python tools/profile_decode.py report <kernel_trace.csv>
+      per-kernel totals of the launches AFTER the last prefill attention kernel, i.e. of the decode steps only
+"""
+import csv
+import collections
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(streams=256, prompt_len=1792, new_tokens=33):
+    sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
+    import torch
+    from mgen import MidiLM, default_decoder
+    dev = torch.device("cuda:0")
+    cfg = default_decoder()
+    model = MidiLM(cfg, device=dev, seed=0)
+    g = torch.Generator().manual_seed(99)
+    prompt = torch.randint(3, 30000, (streams, prompt_len), generator=g).to(dev)
+    out = model.generate(prompt, max_new_tokens=new_tokens, do_sample=True, temperature=0.97, top_k=0, top_p=0.95,
+                         seed=1234)
+    torch.cuda.synchronize()
+    print("generated", tuple(out.shape))
+
+
+def report(path):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    last_prefill = max(i for i, r in enumerate(rows) if "attn_fwd_kernel" in r["Kernel_Name"])
+    dec = rows[last_prefill + 1:]
+    # the prefill's tail (final norm, lm head, first sample) precedes the first decode step: start at the first
+    # decode-attention launch's layer, i.e. drop everything before the first embedding launch after the prefill
+    first = next(i for i, r in enumerate(dec) if "embedding_fwd" in r["Kernel_Name"])
+    dec = dec[first:]
+    steps = sum(1 for r in dec if "embedding_fwd" in r["Kernel_Name"])
+    tot = collections.defaultdict(lambda: [0, 0])
+    for r in dec:
+        t = tot[r["Kernel_Name"][:90]]
+        t[0] += 1
+        t[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    span = int(dec[-1]["End_Timestamp"]) - int(dec[0]["Start_Timestamp"])
+    busy = sum(v[1] for v in tot.values())
+    print(f"decode steps {steps}; wall {span / steps / 1e3:.1f} us/step; kernel time {busy / steps / 1e3:.1f} us/step")
+    for k, (n, ns) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+        print(f"{ns / steps / 1e3:9.1f} us/step  {n / steps:6.1f} launches/step  {ns / n / 1e3:8.1f} us avg  {k}")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(*[int(a) for a in sys.argv[2:]])
+    else:
+        report(sys.argv[2])
