@@ -113,6 +113,88 @@ __global__ __launch_bounds__(256) void ce_kernel(LT* __restrict__ logits, const 
     }
 }
 
+// bf16 rows of up to NT * 8 * NV logits with the whole row held in registers (16 bytes x NV per thread, NT
+// threads): the logits are read from memory once and the gradient written once, instead of read twice. Same
+// arithmetic as ce_kernel; only the order of the partial sums differs.
+template <int NT, int NV, bool WRITE_GRAD>
+__global__ __launch_bounds__(NT) void ce_row_kernel(bf16* __restrict__ logits, const long* __restrict__ labels,
+                                                      long tok0, int V, long ld, int S, long ignore_index,
+                                                      const float* __restrict__ inv_count, float grad_scale,
+                                                      float* __restrict__ row_loss, float* __restrict__ lse_out) {
+    __shared__ float red[2][NT / 64];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const long r = blockIdx.x;
+    const long t = tok0 + r;
+    const int s = (int)(t % S);
+    long label = ignore_index;
+    if (s + 1 < S) label = labels[t + 1];
+    const bool valid = label != ignore_index && label >= 0 && label < V;
+    bf16* row = logits + r * ld;
+    const int nvec = (V + 7) / 8;
+
+    bf16x8 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid + j * NT;
+        if (i < nvec) v[j] = *reinterpret_cast<const bf16x8*>(row + (long)i * 8);
+    }
+    float m = -1.0e30f, sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid + j * NT;
+        if (i < nvec) {
+            float x[8];
+            float mx = m;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[e] = (i * 8 + e < V) ? (float)v[j][e] * LOG2E : -1.0e30f;
+                mx = fmaxf(mx, x[e]);
+            }
+            float acc = sum * __builtin_amdgcn_exp2f(m - mx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(x[e] - mx);
+            sum = acc;
+            m = mx;
+        }
+    }
+    const float wm = wave_max(m);
+    if ((tid & 63) == 0) red[0][wave] = wm;
+    __syncthreads();
+    float M = red[0][0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) M = fmaxf(M, red[0][w]);
+    const float ws = wave_sum(sum * __builtin_amdgcn_exp2f(m - M));
+    if ((tid & 63) == 0) red[1][wave] = ws;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) sum += red[1][w];
+    const float lse = (M + __log2f(sum)) * LN2;
+    if (tid == 0) {
+        if (lse_out) lse_out[t] = lse;
+        row_loss[t] = valid ? (lse - (float)row[label]) : 0.f;
+    }
+    if (!WRITE_GRAD) return;
+    __syncthreads();  // row[label] is read above before anyone overwrites the row
+    const float g = valid ? grad_scale * (*inv_count) : 0.f;
+    const float inv_sum = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = tid + j * NT;
+        if (i < nvec) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int idx = i * 8 + e;
+                float p = __builtin_amdgcn_exp2f((float)v[j][e] * LOG2E - M) * inv_sum;
+                if (idx == label) p -= 1.f;
+                o[e] = (bf16)(idx < V ? p * g : 0.f);
+            }
+            *reinterpret_cast<bf16x8*>(row + (long)i * 8) = o;
+        }
+    }
+}
+
 __global__ void ce_finalize_kernel(const float* __restrict__ row_loss, long T, const float* __restrict__ inv_count,
                                    float* __restrict__ loss) {
     __shared__ double red[256];
@@ -143,7 +225,19 @@ extern "C" int mgen_ce_fwd_bwd(void* logits, const long* labels, long tok0, long
     MGEN_REQUIRE(rows > 0 && V > 0 && S > 0 && ld >= ((V + 7) / 8) * 8 && ld % 8 == 0,
                  "mgen_ce_fwd_bwd: need ld %% 8 == 0 and ld >= V rounded up to 8 (V=%d ld=%ld)", V, ld);
     const dim3 grid((unsigned)rows), block(256);
-#define CE_LAUNCH(TT, WG)                                                                                          \
+    const int nvec = (V + 7) / 8;
+    static const int row_env = [] { const char* e = getenv("MGEN_CE_ROW"); return e ? atoi(e) : 1; }();
+    if (is_bf16 && row_env && nvec > 2048 && nvec <= 512 * 38) {
+        // long bf16 rows (the 151,936-entry vocabulary): one 512-thread block keeps the row in registers
+#define CE_ROW(NV_, WG)                                                                                          \
+    hipLaunchKernelGGL((ce_row_kernel<512, NV_, WG>), grid, dim3(512), 0, stream, (bf16*)logits, labels, tok0, V, ld, S, \
+                       ignore_index, inv_count, grad_scale, row_loss, lse_out)
+        if (nvec <= 512 * 16) { if (write_grad) CE_ROW(16, true); else CE_ROW(16, false); }
+        else { if (write_grad) CE_ROW(38, true); else CE_ROW(38, false); }
+#undef CE_ROW
+        return mgen_check_launch("mgen_ce_fwd_bwd");
+    }
+#define CE_LAUNCH(TT, WG)                                                                                         \
     hipLaunchKernelGGL((ce_kernel<TT, WG>), grid, block, 0, stream, (TT*)logits, labels, tok0, V, ld, S, ignore_index, \
                        inv_count, grad_scale, row_loss, lse_out)
     if (is_bf16) { if (write_grad) CE_LAUNCH(bf16, true); else CE_LAUNCH(bf16, false); }

@@ -336,7 +336,7 @@ def test_embedding(ops):
     assert int(err) == 1
 
 
-@pytest.mark.parametrize("V", [1024, 1031, 30000])
+@pytest.mark.parametrize("V", [1024, 1031, 30000, 65531, 151941])   # the last three: row-in-registers kernel
 def test_cross_entropy(ops, V):
     B, S = 3, 17
     T = B * S
