@@ -9,8 +9,10 @@
 // when the product has enough row tiles, else 128x128 (each wave 64x64). When K is a multiple of 64 the operand
 // tiles go global -> LDS by LDS-DMA into ONE stage (48 or 32 KiB), with 2-4 workgroups per CU covering each other's
 // load latency (a second stage per workgroup costs more in occupancy than it hides: measured); otherwise a
-// register-staged, zero-filling, double-buffered variant is used. Wide products (N >= 1024) with a tile for every CU run on 256x256 tiles with
-// 8 waves and two 64 KiB LDS-DMA stages, one workgroup per CU. An operand whose reduction index is contiguous
+// register-staged, zero-filling, double-buffered variant is used. Wide products (N >= 1024) with a tile for every
+// CU run on 256x256 tiles with 8 waves and two 64 KiB LDS-DMA stages, one workgroup per CU (a persistent form of
+// it that prefetches the next tile under the epilogue measured no faster: reverted). An operand whose reduction
+// index is contiguous
 // in memory lives in LDS as [128 rows][64 k] (row reads); one whose reduction index is the row index lives as
 // [64 k][128 cols] and is read with the transposing LDS read, so no transposed copy of activations or weights is
 // ever made in HBM. Workgroups are numbered so that each XCD (own L2) gets a contiguous range of tiles, grouped 8

@@ -8,7 +8,8 @@ import os
 from ctypes import c_void_p as P, c_int as I, c_long as L, c_float as F, c_ulonglong as U64
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgen_hip.so")
+# MGEN_LIB names another build of the same library (A/B measurements of kernel variants on one machine)
+LIB_PATH = os.environ.get("MGEN_LIB") or os.path.join(_HERE, "libmgen_hip.so")
 
 # name -> argument types (every function returns int, 0 = ok), in the order of include/mgen.h
 SIGNATURES = {
