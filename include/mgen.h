@@ -192,6 +192,13 @@ int mgen_collate_tokens(const long* flat, const long* offsets, const int* prompt
 int mgen_collate_pos4d(const float* rows, long total, const long* chunk_ids, float* pos, float* labels, long* mask,
                        long* ids, int B, int S, mgen_stream_t stream);
 
+/* ---- generated note rows -> MIDI events (notes_to_midi, reference generate_music.py:62-105) -----------------------
+ * rows fp32 [n][4] = (start s, duration s, pitch, velocity); ticks_per_second = tempo / 60 * ticks_per_beat.
+ * ticks[2i] = int(start * tps), ticks[2i+1] = int((start + duration) * tps) (fp32 arithmetic, truncation);
+ * msgs[2i] = 0x90 | pitch << 8 | velocity << 16, msgs[2i+1] = 0x80 | pitch << 8, pitch/velocity clipped to 0..127. */
+int mgen_notes_to_events(const float* rows, long n, float ticks_per_second, int* ticks, int* msgs,
+                         mgen_stream_t stream);
+
 /* dtype conversion: kind 0 fp32 -> bf16, 1 bf16 -> fp32. */
 int mgen_cast(const void* in, void* out, long n, int kind, mgen_stream_t stream);
 

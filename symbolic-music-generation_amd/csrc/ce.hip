@@ -41,19 +41,36 @@ template <> struct Row8<float> {
     }
 };
 
-__global__ void ce_count_kernel(const long* __restrict__ labels, long B, int S, long ignore_index,
-                                float* __restrict__ inv_count, int* __restrict__ count) {
-    __shared__ float red[4];
-    float c = 0.f;
+// One 1024-thread block (the count feeds 1/n on the device, so it stays a single block), four independent loads in
+// flight per thread.
+__global__ __launch_bounds__(1024) void ce_count_kernel(const long* __restrict__ labels, long B, int S,
+                                                        long ignore_index, float* __restrict__ inv_count,
+                                                        int* __restrict__ count) {
+    __shared__ int red[16];
+    int c = 0;
     const long n = B * S;
-    for (long i = threadIdx.x; i < n; i += 256) {
-        const int s = (int)(i % S);
-        if (s + 1 < S && labels[i + 1] != ignore_index) c += 1.f;
+    for (long i0 = threadIdx.x; i0 < n; i0 += 4096) {
+        long lab[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + 1024 * u;
+            lab[u] = (i + 1 < n) ? labels[i + 1] : ignore_index;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + 1024 * u;
+            if (i < n && (int)(i % S) + 1 < S && lab[u] != ignore_index) ++c;
+        }
     }
-    c = block_sum_256(c, red);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        *inv_count = 1.f / c;  // n_valid == 0 gives inf and the mean becomes NaN, as in the reference
-        if (count) *count = (int)c;
+        int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        *inv_count = 1.f / (float)tot;  // n_valid == 0 gives inf and the mean becomes NaN, as in the reference
+        if (count) *count = tot;
     }
 }
 
@@ -195,14 +212,26 @@ __global__ __launch_bounds__(NT) void ce_row_kernel(bf16* __restrict__ logits, c
     }
 }
 
-__global__ void ce_finalize_kernel(const float* __restrict__ row_loss, long T, const float* __restrict__ inv_count,
-                                   float* __restrict__ loss) {
-    __shared__ double red[256];
+// Fixed summation order (thread t adds rows t, t + 1024, ... in double; then a fixed tree): the loss is bitwise
+// reproducible from run to run.
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restrict__ row_loss, long T,
+                                                           const float* __restrict__ inv_count,
+                                                           float* __restrict__ loss) {
+    __shared__ double red[1024];
     double acc = 0.0;
-    for (long i = threadIdx.x; i < T; i += 256) acc += (double)row_loss[i];
+    for (long i0 = threadIdx.x; i0 < T; i0 += 4096) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + 1024 * u;
+            v[u] = i < T ? row_loss[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (double)v[u];
+    }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
+    for (int o = 512; o >= 1; o >>= 1) {
         if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
@@ -214,7 +243,7 @@ __global__ void ce_finalize_kernel(const float* __restrict__ row_loss, long T, c
 extern "C" int mgen_ce_count(const long* labels, long B, int S, long ignore_index, float* inv_count, int* count,
                              hipStream_t stream) {
     MGEN_REQUIRE(labels && inv_count && B > 0 && S > 0, "mgen_ce_count: bad arguments");
-    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, stream, labels, B, S, ignore_index, inv_count, count);
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, B, S, ignore_index, inv_count, count);
     return mgen_check_launch("mgen_ce_count");
 }
 
@@ -248,6 +277,6 @@ extern "C" int mgen_ce_fwd_bwd(void* logits, const long* labels, long tok0, long
 
 extern "C" int mgen_ce_finalize(const float* row_loss, long T, const float* inv_count, float* loss, hipStream_t stream) {
     MGEN_REQUIRE(row_loss && inv_count && loss && T > 0, "mgen_ce_finalize: bad arguments");
-    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, stream, row_loss, T, inv_count, loss);
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, row_loss, T, inv_count, loss);
     return mgen_check_launch("mgen_ce_finalize");
 }

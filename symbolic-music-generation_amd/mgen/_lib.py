@@ -48,6 +48,7 @@ SIGNATURES = {
     "mgen_attn_f32_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, P],
     "mgen_collate_tokens": [P, P, P, P, P, P, I, I, L, I, P],
     "mgen_collate_pos4d": [P, L, P, P, P, P, P, I, I, P],
+    "mgen_notes_to_events": [P, L, F, P, P, P],
     "mgen_cast": [P, P, L, I, P],
     "mgen_ce_count": [P, L, I, L, P, P, P],
     "mgen_ce_fwd_bwd": [P, P, L, L, I, L, I, L, P, F, P, P, I, I, P],

@@ -289,6 +289,12 @@ def collate_pos4d(rows, chunk_ids, pos, labels, mask, ids):
          _stream())
 
 
+def notes_to_events(rows, ticks_per_second, ticks, msgs):
+    """rows fp32 [n, 4]; ticks, msgs int32 [2n]."""
+    _need_gpu(rows, ticks, msgs)
+    call("mgen_notes_to_events", _p(rows), rows.shape[0], float(ticks_per_second), _p(ticks), _p(msgs), _stream())
+
+
 def attn_fwd(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, D, scale, f32=False):
     """q/k/v/out are raw device pointers (ints) of token-major views (bf16, or fp32 with f32=True); strides in
     elements."""
