@@ -111,21 +111,31 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=["default", "aria"], default="default",
+                    help="aria: the ~650M Llama-architecture stand-in of the other benchmark configurations "
+                         "(e.g. --batch 8 --seq 4096, --batch 1 --seq 16384); decode and CPU legs are skipped")
     args = ap.parse_args()
 
-    from mgen import MidiLM, default_decoder, ops
+    from mgen import MidiLM, default_decoder, aria_style_llama, ops
     from mgen.trainer import Trainer, init_distributed_from_env
 
     rank, local, world = init_distributed_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")
     dev = torch.device("cuda", local)
-    cfg = default_decoder()
     B, S = args.batch, args.seq
+    if args.model == "aria":
+        cfg = aria_style_llama()
+        cfg.max_position_embeddings = max(cfg.max_position_embeddings, S)
+        args.decode_tokens, args.no_cpu_baseline = 0, True
+        wl = "Aria-style Llama stand-in (L16 d1536 H24xDh64 I6144 V17727 untied)"
+    else:
+        cfg = default_decoder()
+        wl = "default decoder (MidiQwen shape: L14 d512 H8xDh128 I2048 V151936 tied)"
     model = MidiLM(cfg, device=dev, seed=0)
     trainer = Trainer(model, lr=5e-5, num_epochs=12, steps_per_epoch=1000, warmup=1000, max_grad_norm=1.0)
     g = torch.Generator().manual_seed(1234 + rank)
-    ids = torch.randint(3, 30000, (B, S), generator=g).to(dev)
+    ids = torch.randint(3, min(30000, cfg.vocab_size), (B, S), generator=g).to(dev)
     batch = {"input_ids": ids, "labels": ids}
 
     def barrier():
@@ -178,7 +188,7 @@ def main():
         # FETCH doubled per the gfx950 note), valid for the default workload only
         traffic = None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if (B, S) == (32, 2048) and os.path.exists(pmc):
+        if (B, S) == (32, 2048) and args.model == "default" and os.path.exists(pmc):
             with open(pmc) as fh:
                 traffic = json.load(fh).get("gemm_fwd_bf16_avg_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<TA=0,TB=0,OUT_BF16> (QKV, gate-up, lm_head forward)",
@@ -198,8 +208,7 @@ def main():
             "metric": "train tokens/s", "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "default decoder (MidiQwen shape: L14 d512 H8xDh128 I2048 V151936 tied), "
-                                   f"bf16-mixed full train step, per-GPU batch {B} x seq {S}",
+            "config": {"workload": f"{wl}, bf16-mixed full train step, per-GPU batch {B} x seq {S}",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}"},
             "final_loss": round(float(loss), 4),
             "train_flops_per_token": ftok,
