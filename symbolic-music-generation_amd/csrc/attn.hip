@@ -102,6 +102,22 @@ __device__ __forceinline__ void zero16(f32x16& a) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
+// An accumulation chain of KS MFMAs whose result lands in VGPRs. In a kernel that may use more than 256 registers the
+// compiler puts every MFMA result into the accumulator half of the register file, so a result that vector ALU code
+// consumes (scores, probabilities) costs one copy per register on the way out; written as asm the chain's destination
+// is an ordinary vector register. Nothing inside an asm string is padded by the compiler: the leading s_nop covers a
+// vector-ALU write of an operand just before the first MFMA, the trailing s_nop 11 the 12 wait states between the
+// last MFMA's write and any reader of the result.
+template <int KS>
+__device__ __forceinline__ void mfma_chain_vgpr(f32x16& d, const bf16x8 (&a)[KS], const bf16x8 (&b)[KS]) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a[0]), "v"(b[0]));
+#pragma unroll
+    for (int ks = 1; ks < KS - 1; ++ks)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a[ks]), "v"(b[ks]));
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 11"
+                 : "+v"(d) : "v"(a[KS - 1]), "v"(b[KS - 1]));
+}
+
 // Store a transposed accumulator set acc[db] = X^T[d = 32db + acc_row(reg)][row = lane&31] as X[row][d] (bf16)
 template <int DB>
 __device__ __forceinline__ void store_rows_T(const f32x16 (&acc)[DB], bf16* __restrict__ dst, float mul, int lane) {
@@ -437,7 +453,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     settle_frags<G::KS>(kf);
     settle_frags<G::KS>(vf);
 
-    for (int step = 0; step < nsteps; ++step) {
+    // One step = one 64-query tile. The body exists in a masked and an unmasked form; each form runs in a loop of its
+    // own, so that the loop bodies are straight-line code and the dK/dV accumulators stay in place from step to step
+    // (with both forms behind a branch in one loop the compiler moved all 128 accumulator registers every step).
+    auto run_step = [&](int step, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
         const int cur = step & 1;
         if (step + 1 < nsteps) issue(step + 1, cur ^ 1);
         const int qt0 = (t_first + step % per_head) * 64;
@@ -445,57 +465,63 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
         const char* dOt = Qt + TILE;
         const float* lse_s = reinterpret_cast<const float*>(Qt + 2 * TILE) + 64 * sub;
         const float* del_s = reinterpret_cast<const float*>(Qt + 2 * TILE + 512) + 64 * sub;
-        if (qt0 + 63 >= kw0) {  // wave-uniform: some query of the tile can see some key of this wave
-            auto tile = [&](auto masked) {
-                constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    f32x16 s, dp;
-                    zero16(s);
-                    zero16(dp);
+        for (int u = 0; u < 2; ++u) {
+            f32x16 s, dp;
+            {
+                bf16x8 qa[G::KS], da[G::KS];
 #pragma unroll
-                    for (int ks = 0; ks < G::KS; ++ks)
-                        s = mfma32(frag_row_img256(Qt, 32 * u, ks0 + ks, lane), kf[ks], s);
-#pragma unroll
-                    for (int ks = 0; ks < G::KS; ++ks)
-                        dp = mfma32(frag_row_img256(dOt, 32 * u, ks0 + ks, lane), vf[ks], dp);
-                    // s[reg]: query = qt0 + 32u + acc_row(reg), key = my_k
-                    f32x16 ds;
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int qr = 32 * u + 8 * g4 + 4 * (lane >> 5);
-                        const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qr);
-                        const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + qr);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 4 * g4 + e;
-                            float p = fast_exp2(__builtin_fmaf(s[r], sl2, -lv[e]));
-                            if (MASKED) {
-                                const int q = qt0 + qr + e;
-                                if (my_k > q || q >= S) p = 0.f;
-                            }
-                            s[r] = p;
-                            ds[r] = p * (dp[r] - dl[e]);
-                        }
-                    }
-                    const bf16x8 p0 = acc_to_frag<0>(s), p1 = acc_to_frag<1>(s);
-                    const bf16x8 d0 = acc_to_frag<0>(ds), d1 = acc_to_frag<1>(ds);
-#pragma unroll
-                    for (int db = 0; db < G::DB; ++db) {
-                        // dV^T[d][key] += dO^T[d][q] * P[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
-                        const int c0 = 32 * (db0 + db);
-                        dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u, c0, lane), p0, dv[db]);
-                        dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u + 16, c0, lane), p1, dv[db]);
-                        dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u, c0, lane), d0, dk[db]);
-                        dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u + 16, c0, lane), d1, dk[db]);
-                    }
+                for (int ks = 0; ks < G::KS; ++ks) {
+                    qa[ks] = frag_row_img256(Qt, 32 * u, ks0 + ks, lane);
+                    da[ks] = frag_row_img256(dOt, 32 * u, ks0 + ks, lane);
                 }
-            };
-            if (qt0 < kw0 + 31 || qt0 + 63 >= S) tile(std::true_type{});
-            else tile(std::false_type{});
+                mfma_chain_vgpr<G::KS>(s, qa, kf);
+                mfma_chain_vgpr<G::KS>(dp, da, vf);
+            }
+            // s[reg]: query = qt0 + 32u + acc_row(reg), key = my_k
+            f32x16 ds;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int qr = 32 * u + 8 * g4 + 4 * (lane >> 5);
+                const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qr);
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + qr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    float p = fast_exp2(__builtin_fmaf(s[r], sl2, -lv[e]));
+                    if (MASKED) {
+                        const int q = qt0 + qr + e;
+                        if (my_k > q || q >= S) p = 0.f;
+                    }
+                    s[r] = p;
+                    ds[r] = p * (dp[r] - dl[e]);
+                }
+            }
+            const bf16x8 p0 = acc_to_frag<0>(s), p1 = acc_to_frag<1>(s);
+            const bf16x8 d0 = acc_to_frag<0>(ds), d1 = acc_to_frag<1>(ds);
+#pragma unroll
+            for (int db = 0; db < G::DB; ++db) {
+                // dV^T[d][key] += dO^T[d][q] * P[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
+                const int c0 = 32 * (db0 + db);
+                dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u, c0, lane), p0, dv[db]);
+                dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u + 16, c0, lane), p1, dv[db]);
+                dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u, c0, lane), d0, dk[db]);
+                dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u + 16, c0, lane), d1, dk[db]);
+            }
         }
         if (step + 1 < nsteps) commit(cur ^ 1);
         __syncthreads();
+    };
+    // per head: the tiles that touch the block's diagonal (masked), the tiles below it (every pair visible), and a
+    // last tile that runs past the sequence end (masked) when S is not a multiple of 64
+    const int n_diag = min(per_head, G::ROWS / 64);
+    const int n_tail = ((S & 63) != 0 && per_head > n_diag) ? 1 : 0;
+    int step = 0;
+    for (int hh = 0; hh < group; ++hh) {
+        int j = 0;
+        for (; j < n_diag; ++j, ++step) run_step(step, std::true_type{});
+        for (; j < per_head - n_tail; ++j, ++step) run_step(step, std::false_type{});
+        for (; j < per_head; ++j, ++step) run_step(step, std::true_type{});
     }
     if (my_k < S) {
         store_rows_T<G::DB>(dk, a.dK + (tok0 + my_k) * a.sdk + (long)kvh * HD, a.scale, lane);
