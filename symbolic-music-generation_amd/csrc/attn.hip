@@ -465,20 +465,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
         const char* dOt = Qt + TILE;
         const float* lse_s = reinterpret_cast<const float*>(Qt + 2 * TILE) + 64 * sub;
         const float* del_s = reinterpret_cast<const float*>(Qt + 2 * TILE + 512) + 64 * sub;
+        // all four score / dP chains first: the matrix cores then work through the second half's chains while the
+        // vector ALU does the first half's exponentials
+        f32x16 s[2], dp[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            f32x16 s, dp;
-            {
-                bf16x8 qa[G::KS], da[G::KS];
+            bf16x8 qa[G::KS], da[G::KS];
 #pragma unroll
-                for (int ks = 0; ks < G::KS; ++ks) {
-                    qa[ks] = frag_row_img256(Qt, 32 * u, ks0 + ks, lane);
-                    da[ks] = frag_row_img256(dOt, 32 * u, ks0 + ks, lane);
-                }
-                mfma_chain_vgpr<G::KS>(s, qa, kf);
-                mfma_chain_vgpr<G::KS>(dp, da, vf);
+            for (int ks = 0; ks < G::KS; ++ks) {
+                qa[ks] = frag_row_img256(Qt, 32 * u, ks0 + ks, lane);
+                da[ks] = frag_row_img256(dOt, 32 * u, ks0 + ks, lane);
             }
-            // s[reg]: query = qt0 + 32u + acc_row(reg), key = my_k
+            mfma_chain_vgpr<G::KS>(s[u], qa, kf);
+            mfma_chain_vgpr<G::KS>(dp[u], da, vf);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // column fragments of both transposed products, issued ahead of the exponentials that hide their latency
+            bf16x8 dot[G::DB][2], qtf[G::DB][2];
+#pragma unroll
+            for (int db = 0; db < G::DB; ++db) {
+                const int c0 = 32 * (db0 + db);
+                dot[db][0] = frag_col_img256<true>(dOt, 32 * u, c0, lane);
+                dot[db][1] = frag_col_img256<true>(dOt, 32 * u + 16, c0, lane);
+                qtf[db][0] = frag_col_img256<true>(Qt, 32 * u, c0, lane);
+                qtf[db][1] = frag_col_img256<true>(Qt, 32 * u + 16, c0, lane);
+            }
+            // s[u][reg]: query = qt0 + 32u + acc_row(reg), key = my_k
             f32x16 ds;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -488,25 +501,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    float p = fast_exp2(__builtin_fmaf(s[r], sl2, -lv[e]));
+                    float p = fast_exp2(__builtin_fmaf(s[u][r], sl2, -lv[e]));
                     if (MASKED) {
                         const int q = qt0 + qr + e;
                         if (my_k > q || q >= S) p = 0.f;
                     }
-                    s[r] = p;
-                    ds[r] = p * (dp[r] - dl[e]);
+                    s[u][r] = p;
+                    ds[r] = p * (dp[u][r] - dl[e]);
                 }
             }
-            const bf16x8 p0 = acc_to_frag<0>(s), p1 = acc_to_frag<1>(s);
+            const bf16x8 p0 = acc_to_frag<0>(s[u]), p1 = acc_to_frag<1>(s[u]);
             const bf16x8 d0 = acc_to_frag<0>(ds), d1 = acc_to_frag<1>(ds);
 #pragma unroll
             for (int db = 0; db < G::DB; ++db) {
                 // dV^T[d][key] += dO^T[d][q] * P[q][key] ; dK^T[d][key] += Q^T[d][q] * dS[q][key]
-                const int c0 = 32 * (db0 + db);
-                dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u, c0, lane), p0, dv[db]);
-                dv[db] = mfma32(frag_col_img256<true>(dOt, 32 * u + 16, c0, lane), p1, dv[db]);
-                dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u, c0, lane), d0, dk[db]);
-                dk[db] = mfma32(frag_col_img256<true>(Qt, 32 * u + 16, c0, lane), d1, dk[db]);
+                dv[db] = mfma32(dot[db][0], p0, dv[db]);
+                dv[db] = mfma32(dot[db][1], p1, dv[db]);
+                dk[db] = mfma32(qtf[db][0], d0, dk[db]);
+                dk[db] = mfma32(qtf[db][1], d1, dk[db]);
             }
         }
         if (step + 1 < nsteps) commit(cur ^ 1);
