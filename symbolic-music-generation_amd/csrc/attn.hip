@@ -357,13 +357,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < G::KS; ++ks)
                     dp = mfma32(frag_row_img256(Vt, 32 * t, ks0 + ks, lane), dof[ks], dp);
+                // key = kv0 + 32t + acc_row(r, lane) is masked when key > my_q; acc_row = c_r + 4*(lane>>5) with c_r a
+                // constant of the register, so one per-lane threshold serves all 16 compares (no mask: threshold
+                // beyond every c_r)
+                const int thr = need_mask ? my_q - kv0 - 32 * t - 4 * (lane >> 5) : 64;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float p = fast_exp2(__builtin_fmaf(s[r], sl2, -lse2));
-                    if (need_mask) {
-                        const int key = kv0 + 32 * t + acc_row(r, lane);
-                        if (key > my_q) p = 0.f;
-                    }
+                    if ((r & 3) + 8 * (r >> 2) > thr) p = 0.f;
                     s[r] = p * (dp[r] - delta);  // dS^T[key][q]
                 }
                 const bf16x8 f0 = acc_to_frag<0>(s), f1 = acc_to_frag<1>(s);
