@@ -34,7 +34,9 @@ int mgen_device_info(int device, char* name, int name_len);
  * transB=0: B stored [N][ldb>=K8]; transB=1: B stored [K][ldb>=N8]. (X8 = X rounded up to 8; padding columns of a
  * k-contiguous operand must hold zeros.)
  * out_mode: 0 bf16 store, 1 fp32 store, 2 fp32 accumulate (C += ...), 3 fp32 C = resid + float(bf16(acc))
- * (residual add of a bf16 projection output, TF models/qwen3/modeling_qwen3.py:316,322), 4 fp32 C = resid + acc. */
+ * (residual add of a bf16 projection output, TF models/qwen3/modeling_qwen3.py:316,322), 4 fp32 C = resid + acc,
+ * 6 bf16 C = bf16(float(C) + acc) (a low-rank adapter's product added to its base layer's output: the LoRA mode of
+ * the reference, src/model/model.py:251-271). */
 int mgen_gemm_bf16(const void* A, const void* B, void* C, const void* resid, int M, int N, int K, long lda, long ldb,
                    long ldc, long ldr, int transA, int transB, int out_mode, float alpha, mgen_stream_t stream);
 

@@ -25,7 +25,8 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
 
 enum OutMode { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_F32_RESID_BF16ROUND = 3, OUT_F32_RESID = 4,
-               OUT_F32_ATOMIC = 5 /* internal: split-K form of OUT_F32_ACC */ };
+               OUT_F32_ATOMIC = 5 /* internal: split-K form of OUT_F32_ACC */,
+               OUT_BF16_ACC = 6 /* C (bf16) = bf16(C + product): low-rank adapter paths, 128x128 tiles only */ };
 
 struct GemmArgs {
     const bf16* A;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256 * WM, WM == 2 ? 2 : (GLDS ? (NJ == 4 ? 2 : 3) :
                     for (int e = 0; e < 4; ++e) acc[i][j][4 * g4 + e] += b[e];
             }
     }
-    if (MODE == OUT_BF16 && (g.ldc & 7) == 0) {
+    if ((MODE == OUT_BF16 || MODE == OUT_BF16_ACC) && (g.ldc & 7) == 0) {
         // bf16 output through LDS: the wave parks its 64x64 sub-tile in its own 8 KiB of the (now idle) staging
         // area as [64 rows][128 bytes] with the 16-byte chunks XOR-swizzled by row, then writes whole 128-byte row
         // segments with 16 bytes per lane (8 store instructions per lane instead of 32 scattered 8-byte ones).
@@ -330,19 +331,29 @@ __global__ __launch_bounds__(256 * WM, WM == 2 ? 2 : (GLDS ? (NJ == 4 ? 2 : 3) :
                 if (m < g.M && n < g.N) {
                     bf16* c = C + (long)m * g.ldc + n;
                     if (n + 7 < g.N) {
-                        *reinterpret_cast<u32x4*>(c) = v;
+                        if (MODE == OUT_BF16_ACC) {   // bf16(old + bf16(product)), 16 bytes at a time
+                            const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+                            const bf16x8 old = *reinterpret_cast<const bf16x8*>(c);
+                            bf16x8 sum;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sum[e] = (bf16)((float)old[e] + (float)b[e]);
+                            *reinterpret_cast<bf16x8*>(c) = sum;
+                        } else {
+                            *reinterpret_cast<u32x4*>(c) = v;
+                        }
                     } else {
                         const bf16x8 b = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            if (n + e < g.N) c[e] = b[e];
+                            if (n + e < g.N)
+                                c[e] = MODE == OUT_BF16_ACC ? (bf16)((float)c[e] + (float)b[e]) : b[e];
                     }
                 }
             }
         }
         return;
     }
-    if (MODE != OUT_BF16 && (g.ldc & 3) == 0 && (g.N & 3) == 0 &&
+    if (MODE != OUT_BF16 && MODE != OUT_BF16_ACC && (g.ldc & 3) == 0 && (g.N & 3) == 0 &&
         ((MODE != OUT_F32_RESID_BF16ROUND && MODE != OUT_F32_RESID) || (g.ldr & 3) == 0)) {
         // fp32 output through LDS, 32 rows at a time: [32 rows][256 bytes] per wave, 16-byte chunks XOR-swizzled by
         // row; then whole 256-byte row segments are combined with the old value / residual and stored, 16 B per lane.
@@ -402,8 +413,12 @@ __global__ __launch_bounds__(256 * WM, WM == 2 ? 2 : (GLDS ? (NJ == 4 ? 2 : 3) :
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g4 + e] * g.alpha;
                 const bool full = (n + 3 < g.N);
-                if (MODE == OUT_BF16) {
+                if (MODE == OUT_BF16 || MODE == OUT_BF16_ACC) {
                     bf16* c = reinterpret_cast<bf16*>(g.C) + (long)m * g.ldc + n;
+                    if (MODE == OUT_BF16_ACC) {
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < g.N) v[e] += (float)c[e];
+                    }
                     if (full && ((g.ldc & 3) == 0)) {
                         bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
                         *reinterpret_cast<bf16x4*>(c) = o;
@@ -466,6 +481,10 @@ int launch_mode(const GemmArgs& g, int mode, hipStream_t s) {
         case OUT_F32_RESID_BF16ROUND: return launch_one<TA, TB, OUT_F32_RESID_BF16ROUND, GLDS, NJ, WM>(g, s);
         case OUT_F32_RESID: return launch_one<TA, TB, OUT_F32_RESID, GLDS, NJ, WM>(g, s);
         case OUT_F32_ATOMIC: return launch_one<TA, TB, OUT_F32_ATOMIC, GLDS, NJ, WM>(g, s);
+        case OUT_BF16_ACC:
+            if constexpr (NJ == 2 && WM == 1) return launch_one<TA, TB, OUT_BF16_ACC, GLDS, NJ, WM>(g, s);
+            mgen_set_error("mgen_gemm_bf16: OUT_BF16_ACC runs on 128x128 tiles only");
+            return MGEN_EINVAL;
         default: mgen_set_error("mgen_gemm_bf16: unknown out_mode %d", mode); return MGEN_EINVAL;
     }
 }
@@ -498,7 +517,8 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.R = (const float*)resid; g.bias = (const bf16*)bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.nbm = (M + BM - 1) / BM; g.nbn = (N + BN - 1) / BN;
-    MGEN_REQUIRE(out_mode >= 0 && out_mode <= OUT_F32_RESID, "mgen_gemm_bf16: unknown out_mode %d", out_mode);
+    MGEN_REQUIRE((out_mode >= 0 && out_mode <= OUT_F32_RESID) || out_mode == OUT_BF16_ACC,
+                 "mgen_gemm_bf16: unknown out_mode %d", out_mode);
     const bool glds = (K % BK) == 0;
     // 256-wide workgroup tiles (64x128 per wave) when they still give every CU at least two workgroups
     static const int wide_env = [] { const char* e = getenv("MGEN_GEMM_WIDE"); return e ? atoi(e) : -1; }();
@@ -506,13 +526,14 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     // forward is store-bound per tile and stays on 128-wide tiles)
     bool wide = glds && slabs <= 1 && N >= 256 && (long)g.nbm * ((N + 255) / 256) >= 512 &&
                 !(K <= 512 && N >= 65536);
-    if (wide_env == 0) wide = false;
+    if (wide_env == 0 || out_mode == OUT_BF16_ACC) wide = false;
     // 256x256 tiles, one workgroup per CU, for products with at least four column tiles and a tile for every CU
     // (MGEN_GEMM_WIDE=1: never). Measured against the 128x256 tiles: +12 % on 8192^3, +3..6 % on the decoder's
     // N >= 1024 products, -5..10 % on its N = 512 ones (two tile columns leave no second workgroup per CU to
     // cover the first K step and the epilogue).
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const bool big = glds && slabs <= 1 && wide_env != 0 && wide_env != 1 && tiles256 >= 256 && N >= 1024 &&
+                     out_mode != OUT_BF16_ACC &&
                      (out_mode != OUT_F32_ACC || tiles256 >= 512);
     if (big) { wide = false; g.nbm = (M + 255) / 256; }
     if (wide || big) g.nbn = (N + 255) / 256;

@@ -119,6 +119,10 @@ class GenerationMixin:
             raise ValueError("generate() needs input_ids of shape [batch, prompt_len]")
         if not input_ids.is_cuda:
             raise RuntimeError("MidiLM runs on the GPU only: input_ids must be a CUDA/HIP tensor")
+        if getattr(self, "lora", None) is not None and use_cache:
+            # the one-token decode path reads the base weights only: fold the adapters in, or decode without a cache
+            raise RuntimeError("the model carries low-rank adapters: call merge_lora() before generate(), or pass "
+                               "use_cache=False")
         cfg = self.cfg
         B, P = input_ids.shape
         if max_new_tokens is None:

@@ -1,0 +1,133 @@
+"""Low-rank adapters (LoRA) on the decoder's projections: the other training mode of the reference.
+
+Reference: `MidiAria.to_lora` (/root/reference/src/model/model.py:251-271) freezes every base weight and wraps the
+model with peft's `LoraConfig(r=32, lora_alpha=64, lora_dropout=0.05, bias="none")` on the fused QKV projection, the
+attention output projection and the gate / up / down projections. peft's linear layer computes
+`base(x) + lora_B(lora_A(dropout(x))) * (alpha / r)` with A ~ kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in))
+and B = 0. peft is not installed here: the arithmetic is restated from that formula (parity unpinned); the adapter
+dropout is not applied (p = 0), as for the other dropouts of this build.
+
+Here the adapters live in one small flat fp32 buffer (+ gradient, + bf16 shadow) next to the frozen model. Each site
+costs two extra products in the forward pass, t = s * x A^T (N = r) and y += t B^T (K = r, added straight into the
+base projection's output by the GEMM epilogue), and four in the backward pass (dt = s * dy B, dB += dy^T t,
+dA += dt^T x, dx += dt A); the base weights get no gradient products at all.
+"""
+import math
+
+import torch
+
+from . import ops
+
+SITES = ("qkv", "o", "gate", "up", "down")
+_NAMES = {"qkv": "self_attn.qkv_proj", "o": "self_attn.o_proj", "gate": "mlp.gate_proj", "up": "mlp.up_proj",
+          "down": "mlp.down_proj"}
+
+
+class _Site:
+    __slots__ = ("A", "B", "gA", "gB", "sA", "sB")
+
+
+class LoraAdapters:
+    def __init__(self, model, r=32, alpha=64, seed=0):
+        cfg = model.cfg
+        if r % 8 or r <= 0:
+            raise ValueError("the adapter rank must be a positive multiple of 8")
+        if cfg.arch != "llama" or cfg.pos4d or model.act_dtype != torch.bfloat16:
+            raise NotImplementedError("adapters cover the bf16-mixed token models with RMSNorm/RoPE/SwiGLU blocks")
+        self.r, self.alpha, self.scale = r, alpha, alpha / r
+        d, I = cfg.hidden_size, cfg.intermediate_size
+        NQ, HD = cfg.qkv_width, cfg.num_attention_heads * cfg.head_dim
+        # (in, out) of every site; gate and up sit back to back so that one product with [A_gate; A_up] serves both
+        self.dims = {"qkv": (d, NQ), "o": (HD, d), "gate": (d, I), "up": (d, I), "down": (I, d)}
+        per_layer = sum(r * i + o * r for i, o in self.dims.values())
+        L = cfg.num_hidden_layers
+        dev = model.flat_param.device
+        self.flat_param = torch.zeros(L * per_layer, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros_like(self.flat_param)
+        self.flat_shadow = torch.zeros(L * per_layer, dtype=torch.bfloat16, device=dev)
+        self._shadow_version = -1
+        self.layers = []
+        self._names = {}
+        off = 0
+        g = torch.Generator(device=dev).manual_seed(seed)
+        for l in range(L):
+            sites = {}
+            # A blocks first (gate and up adjacent), then the B blocks
+            order = [("qkv", "A"), ("o", "A"), ("gate", "A"), ("up", "A"), ("down", "A"),
+                     ("qkv", "B"), ("o", "B"), ("gate", "B"), ("up", "B"), ("down", "B")]
+            for k in SITES:
+                sites[k] = _Site()
+            for k, which in order:
+                i, o = self.dims[k]
+                shape = (r, i) if which == "A" else (o, r)
+                n = shape[0] * shape[1]
+                for tag, flat in (("", self.flat_param), ("g", self.flat_grad), ("s", self.flat_shadow)):
+                    setattr(sites[k], tag + which, flat[off:off + n].view(shape))
+                if which == "A":
+                    bound = 1.0 / math.sqrt(i)
+                    sites[k].A.uniform_(-bound, bound, generator=g)
+                self._names[f"model.layers.{l}.{_NAMES[k]}.lora_{which}.weight"] = getattr(sites[k], which)
+                off += n
+            # [A_gate; A_up] as one [2r, d] operand (the two blocks are adjacent in the flat buffers)
+            sites["gu_sA"] = self.flat_shadow[sites["gate"].sA.storage_offset():][:2 * r * d].view(2 * r, d)
+            sites["gu_gA"] = self.flat_grad[sites["gate"].gA.storage_offset():][:2 * r * d].view(2 * r, d)
+            self.layers.append(sites)
+        # a differentiable input for the model's autograd node while every base parameter is frozen
+        self.anchor = torch.nn.Parameter(self.flat_param[:8])
+
+    # ---- parameter store protocol shared with MidiLM (what FusedAdamW and the gradient reducer use) ----------
+    def sync_shadow(self):
+        if self._shadow_version != self.flat_param._version:
+            ops.cast(self.flat_param, self.flat_shadow)
+            self._shadow_version = self.flat_param._version
+
+    def mark_shadow_fresh(self):
+        self._shadow_version = self.flat_param._version
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self._names.items()}
+
+    def load_state_dict(self, sd):
+        missing = [k for k in self._names if k not in sd]
+        if missing:
+            raise RuntimeError(f"adapter state dict misses {missing[:4]} ...")
+        with torch.no_grad():
+            for k, v in self._names.items():
+                v.copy_(sd[k].to(device=v.device, dtype=torch.float32))
+        self._shadow_version = -1
+
+    def named_parameters(self):
+        return list(self._names.items())
+
+    # ---- one site ------------------------------------------------------------------------------------------
+    def fwd(self, x, sA, sB, y, n_in, n_out, r_cols=None):
+        """t = s * x A^T (returned, bf16 [T, rows of A]); y[:, :n_out] += t B^T. `y` is the base projection's output:
+        bf16, or the fp32 residual stream."""
+        T = x.shape[0]
+        rr = sA.shape[0]
+        t = torch.empty(T, rr, dtype=torch.bfloat16, device=x.device)
+        ops.gemm(x, sA, t, T, rr, n_in, x.stride(0), sA.stride(0), rr, alpha=self.scale)
+        if sB is not None:
+            self.add_out(t, sB, y, n_out)
+        return t
+
+    def add_out(self, t, sB, y, n_out):
+        T = t.shape[0]
+        mode = ops.OUT_F32_ACC if y.dtype == torch.float32 else ops.OUT_BF16_ACC
+        ops.gemm(t, sB, y, T, n_out, self.r, t.stride(0), sB.stride(0), y.stride(0), out_mode=mode)
+
+    def bwd(self, dy, x, t, sA, sB, gA, gB, dx, n_in, n_out):
+        """dy [T, n_out] (bf16), x [T, n_in], t from fwd. Accumulates gA, gB; adds the adapter's share to dx (which
+        already holds dy W)."""
+        T = dy.shape[0]
+        r = self.r
+        dt = torch.empty(T, r, dtype=torch.bfloat16, device=dy.device)
+        ops.gemm(dy, sB, dt, T, r, n_out, dy.stride(0), sB.stride(0), r, trans_b=True, alpha=self.scale)
+        ops.gemm(dy, t, gB, n_out, r, T, dy.stride(0), t.stride(0), gB.stride(0), True, True, ops.OUT_F32_ACC)
+        ops.gemm(dt, x, gA, r, n_in, T, r, x.stride(0), gA.stride(0), True, True, ops.OUT_F32_ACC)
+        if dx is not None:
+            ops.gemm(dt, sA, dx, T, n_in, r, r, sA.stride(0), dx.stride(0), False, True, ops.OUT_BF16_ACC)
+        return dt

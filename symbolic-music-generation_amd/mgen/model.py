@@ -140,6 +140,7 @@ class MidiLM(GenerationMixin, nn.Module):
         self._rope_cs = None
         self._rope_npos = 0
         self._lm_grad_tmp = None
+        self.lora = None        # low-rank adapters (to_lora): then the base weights are frozen
         self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
         if seed is not None:
             self.init_weights(seed)
@@ -164,7 +165,45 @@ class MidiLM(GenerationMixin, nn.Module):
 
     def _anchor(self):
         """A parameter handed to the autograd node so that it has a differentiable input."""
+        if self.lora is not None:
+            return self.lora.anchor
         return self.lm_head.weight
+
+    # ------------------------------------------------------------------------------------------------
+    # low-rank adapters
+    # ------------------------------------------------------------------------------------------------
+    def to_lora(self, r: int = 32, lora_alpha: int = 64, seed: int = 0):
+        """`MidiAria.to_lora` (/root/reference/src/model/model.py:251-271): freeze every base weight and train
+        rank-r adapters on the fused QKV, attention output, gate, up and down projections. Returns the adapter
+        store (its flat buffers are what the fused optimizer and the gradient reducer then work on)."""
+        from .lora import LoraAdapters
+        if self.lora is not None:
+            raise RuntimeError("the model already carries adapters")
+        for prm in self.parameters():
+            prm.requires_grad = False
+        self.lora = LoraAdapters(self, r, lora_alpha, seed)
+        return self.lora
+
+    def merge_lora(self):
+        """Fold the adapters into the base weights (W += (alpha / r) B A, fp32) and drop them: the form generate()
+        and checkpoints of the plain model use."""
+        lo = self.lora
+        if lo is None:
+            return
+        lo.sync_shadow()
+        for l, v in enumerate(self._layers):
+            st = lo.layers[l]
+            I = self.cfg.intermediate_size
+            targets = (("qkv", v.w_qkv), ("o", v.w_o), ("gate", v.w_gu[:I]), ("up", v.w_gu[I:]), ("down", v.w_down))
+            for k, W in targets:
+                n_in, n_out = lo.dims[k]
+                # W[out, in] += s * B[out, r] A[r, in]: A is stored [K = r][N = in]
+                ops.gemm(st[k].sB, st[k].sA, W, n_out, n_in, lo.r, lo.r, n_in, W.stride(0), False, True,
+                         ops.OUT_F32_ACC, alpha=lo.scale)
+        self.lora = None
+        self._shadow_version = -1
+        for prm in self.parameters():
+            prm.requires_grad = True
 
     def _view(self, flat, name, shape=None, count=None):
         shape = shape or self._shapes[name]
@@ -307,6 +346,8 @@ class MidiLM(GenerationMixin, nn.Module):
         if labels is not None:
             labels = labels.contiguous().to(torch.int64)
         self.sync_shadow()
+        if self.lora is not None:
+            self.lora.sync_shadow()
         if labels is not None and torch.is_grad_enabled():
             loss = _LMTrainFunction.apply(self, input_ids, labels, self._anchor())
             return CausalLMOutput(loss=loss, logits=None)
@@ -414,12 +455,16 @@ class MidiLM(GenerationMixin, nn.Module):
         else:
             cs = self._rope_table(S)
             ops.embedding_fwd(inp, self.model.embed_tokens.weight, h, self._err_flag)
+        lo = self.lora
         for l, v in enumerate(self._layers):
+            la = lo.layers[l] if lo is not None else None
             x1 = torch.empty(T, d, dtype=bf, device=dev)
             rstd1 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h, v.w_ln1, x1, rstd1, cfg.rms_norm_eps)
             qkv = torch.empty(T, NQ, dtype=bf, device=dev)
             ops.linear_fwd(x1, v.s_qkv, qkv)
+            if la is not None:   # adapters: y += s (x A^T) B^T, added into the base projection's output
+                t_qkv = lo.fwd(x1, la["qkv"].sA, la["qkv"].sB, qkv, d, NQ)
             if cfg.pos4d:
                 # q, k (normalised) and v all rotated: one [T, NQ] buffer in the layout of qkv
                 qk = torch.empty(T, NQ, dtype=bf, device=dev)
@@ -444,17 +489,26 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.rotate4d(att, att_o, cs, T, H, Dh, inverse=True)
             h_mid = torch.empty(T, d, dtype=torch.float32, device=dev)
             ops.linear_fwd(att_o, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
+            if la is not None:
+                t_o = lo.fwd(att_o, la["o"].sA, la["o"].sB, h_mid, H * Dh, d)
             x2 = torch.empty(T, d, dtype=bf, device=dev)
             rstd2 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h_mid, v.w_ln2, x2, rstd2, cfg.rms_norm_eps)
             gu = torch.empty(T, 2 * I, dtype=bf, device=dev)
             ops.linear_fwd(x2, v.s_gu, gu)
+            if la is not None:   # one product with [A_gate; A_up], then each half through its own B
+                t_gu = lo.fwd(x2, la["gu_sA"], None, None, d, 0)
+                lo.add_out(t_gu[:, :lo.r], la["gate"].sB, gu[:, :I], I)
+                lo.add_out(t_gu[:, lo.r:], la["up"].sB, gu[:, I:], I)
             act = torch.empty(T, I, dtype=bf, device=dev)
             ops.swiglu_fwd(gu, act)
             h_out = torch.empty(T, d, dtype=torch.float32, device=dev)
             ops.linear_fwd(act, v.s_down, h_out, ops.OUT_F32_RESID_BF16ROUND, h_mid)
+            if la is not None:
+                t_down = lo.fwd(act, la["down"].sA, la["down"].sB, h_out, I, d)
             if save is not None:
-                save.append((h, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o))
+                save.append((h, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o,
+                             (t_qkv, t_o, t_gu, t_down) if la is not None else None))
             h = h_out
         xN = torch.empty(T, d, dtype=bf, device=dev)
         rstdN = torch.empty(T, dtype=torch.float32, device=dev)
@@ -492,7 +546,9 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.gemm_any(dl, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
                 # the weight-gradient product runs over 8192 tokens per launch: its workgroups stream the whole
                 # reduction range and stay in step (sharing the activation rows in L2) only over a short range
-                if isinstance(dl, ops.W2):
+                if self.lora is not None:
+                    pass   # frozen base: no weight gradient for the head
+                elif isinstance(dl, ops.W2):
                     ops.gemm_any(dl, xc, self._lm_grad_tmp, V, d, n, ld, xc.stride(0), d, True, True,
                                  ops.OUT_F32 if first else ops.OUT_F32_ACC)
                     first = False
@@ -523,6 +579,7 @@ class MidiLM(GenerationMixin, nn.Module):
         QK = (H + KVH) * Dh
         scale = Dh ** -0.5
         h_last, rstdN, cs = final
+        lo = self.lora
         dh = torch.empty(T, d, dtype=torch.float32, device=dev)
         dh_lp = torch.empty(T, d, dtype=bf, device=dev)
         g_norm = self._view(self.flat_grad, "model.norm.weight")
@@ -537,17 +594,30 @@ class MidiLM(GenerationMixin, nn.Module):
         delta = torch.empty(B, H, S, dtype=torch.float32, device=dev)
         for l in range(cfg.num_hidden_layers - 1, -1, -1):
             v = self._layers[l]
-            h_in, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o = saved[l]
+            h_in, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o, lts = saved[l]
+            la = lo.layers[l] if lo is not None else None   # adapters: the base weights are frozen (no wgrad)
             # ---- MLP branch
             ops.linear_dgrad(dh_lp, v.s_down, dact)
-            ops.linear_wgrad(dh_lp, act, v.g_down)
+            if la is None:
+                ops.linear_wgrad(dh_lp, act, v.g_down)
+            else:
+                lo.bwd(dh_lp, act, lts[3], la["down"].sA, la["down"].sB, la["down"].gA, la["down"].gB, dact, I, d)
             ops.swiglu_bwd(gu, dact, dgu)
             ops.linear_dgrad(dgu, v.s_gu, dx)
-            ops.linear_wgrad(dgu, x2, v.g_gu)
+            if la is None:
+                ops.linear_wgrad(dgu, x2, v.g_gu)
+            else:
+                r_ = lo.r
+                lo.bwd(dgu[:, :I], x2, lts[2][:, :r_], la["gate"].sA, la["gate"].sB, la["gate"].gA, la["gate"].gB,
+                       dx, d, I)
+                lo.bwd(dgu[:, I:], x2, lts[2][:, r_:], la["up"].sA, la["up"].sB, la["up"].gA, la["up"].gB, dx, d, I)
             ops.rmsnorm_bwd(dx, h_mid, v.w_ln2, rstd2, dh, dh_lp, v.g_ln2, accumulate=True)
             # ---- attention branch
             ops.linear_dgrad(dh_lp, v.s_o, datt)
-            ops.linear_wgrad(dh_lp, att_o, v.g_o)
+            if la is None:
+                ops.linear_wgrad(dh_lp, att_o, v.g_o)
+            else:
+                lo.bwd(dh_lp, att_o, lts[1], la["o"].sA, la["o"].sB, la["o"].gA, la["o"].gB, datt, H * Dh, d)
             dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + esz * H * Dh, dqkv.data_ptr() + esz * QK
             if cfg.pos4d:
                 # datt is the gradient of the rotated-back output: rotate it forward to reach the attention output
@@ -566,12 +636,15 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.qknorm_rope_bwd(dqp, NQ, dqp, dkp, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn, cs, None, S,
                                     T, H, KVH, Dh, cfg.rms_norm_eps, is_bf16=not f32)
             ops.linear_dgrad(dqkv, v.s_qkv, dx)
-            ops.linear_wgrad(dqkv, x1, v.g_qkv)
+            if la is None:
+                ops.linear_wgrad(dqkv, x1, v.g_qkv)
+            else:
+                lo.bwd(dqkv, x1, lts[0], la["qkv"].sA, la["qkv"].sB, la["qkv"].gA, la["qkv"].gB, dx, d, NQ)
             ops.rmsnorm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, accumulate=True)
             saved[l] = None
             if grad_hook is not None:
                 grad_hook(l)
-        if not cfg.pos4d:  # the 4-D model's input is a constant: nothing to train below layer 0
+        if not cfg.pos4d and lo is None:  # (4-D model: constant input; adapters: frozen embedding)
             ops.embedding_bwd(inp, dh, self._view(self.flat_grad, "model.embed_tokens.weight"))
             if grad_hook is not None:
                 grad_hook("embed")
@@ -618,8 +691,9 @@ class _LMTrainFunction(torch.autograd.Function):
             ops.scale_(dxN, 1.0, go)
         else:
             ops.scale_bf16_(dxN, 1.0, go)
-        name = model._lm_head_name()
-        ops.axpy_(model._view(model.flat_grad, name).view(-1), model._lm_grad_tmp.view(-1), 1.0, go)
+        if model.lora is None:   # (frozen base: the head's weight gradient was not formed)
+            name = model._lm_head_name()
+            ops.axpy_(model._view(model.flat_grad, name).view(-1), model._lm_grad_tmp.view(-1), 1.0, go)
         model._backward_layers(ctx.input_ids, ctx.saved, ctx.final, dxN, getattr(model, "_grad_hook", None))
         ctx.saved = None
         for pname, prm in model.named_parameters():

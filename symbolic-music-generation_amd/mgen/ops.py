@@ -7,6 +7,7 @@ from ._lib import call
 
 # GEMM epilogues (must match csrc/gemm.hip)
 OUT_BF16, OUT_F32, OUT_F32_ACC, OUT_F32_RESID_BF16ROUND, OUT_F32_RESID = 0, 1, 2, 3, 4
+OUT_BF16_ACC = 6   # bf16 C = bf16(C + product)
 
 
 def _stream():

@@ -19,10 +19,14 @@ class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0):
         self.model = model
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        super().__init__([p for p in model.parameters()], defaults)
-        dev = model.flat_param.device
-        self.exp_avg = torch.zeros_like(model.flat_param)
-        self.exp_avg_sq = torch.zeros_like(model.flat_param)
+        # with low-rank adapters (model.to_lora()) the base is frozen and the adapter store is what gets trained:
+        # it has the same flat_param / flat_grad / flat_shadow protocol
+        self.store = model.lora if getattr(model, "lora", None) is not None else model
+        params = [self.store.anchor] if self.store is not model else [p for p in model.parameters()]
+        super().__init__(params, defaults)
+        dev = self.store.flat_param.device
+        self.exp_avg = torch.zeros_like(self.store.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.store.flat_param)
         self.max_grad_norm = float(max_grad_norm)
         self._ws = torch.empty(lib().mgen_sumsq_partial_count(), dtype=torch.float64, device=dev)
         self.norm_and_coef = torch.ones(2, dtype=torch.float32, device=dev)  # {total norm, clip coefficient}
@@ -33,7 +37,7 @@ class FusedAdamW(torch.optim.Optimizer):
         """Computes the total gradient L2 norm and the clip coefficient on the device; the scaling itself is
         folded into the update kernel. Returns the (device) norm tensor."""
         mn = self.max_grad_norm if max_norm is None else float(max_norm)
-        ops.grad_norm_clip(self.model.flat_grad, mn, self._ws, self.norm_and_coef)
+        ops.grad_norm_clip(self.store.flat_grad, mn, self._ws, self.norm_and_coef)
         return self.norm_and_coef[0]
 
     @torch.no_grad()
@@ -48,7 +52,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.max_grad_norm > 0:
             self.clip_grad_norm_()
             clip = self.norm_and_coef
-        m = self.model
+        m = self.store
         ops.adamw_step(m.flat_param, m.flat_grad, self.exp_avg, self.exp_avg_sq, m.flat_shadow, clip,
                        float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count)
         m.mark_shadow_fresh()
@@ -56,6 +60,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False):
         self.model.zero_grad()
+        if self.store is not self.model:
+            self.store.zero_grad()
 
 
 def get_optim(model, lr, num_epochs, steps_per_epoch, warmup=1000, end_ratio=0.1, max_grad_norm=1.0):

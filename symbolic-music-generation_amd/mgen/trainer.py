@@ -31,7 +31,8 @@ class GradReducer:
         self._ranges = {tag: (s, e) for tag, s, e in model.grad_ranges()}
         # RCCL averages in the collective; gloo (CPU rehearsal of the same logic) has no AVG: sum, then divide
         self._native_avg = self.world > 1 and dist.get_backend(group) == "nccl"
-        if self.world > 1:
+        self._lora = getattr(model, "lora", None)   # adapters: one small buffer, reduced in wait()
+        if self.world > 1 and self._lora is None:
             model._grad_hook = self._on_range_done
 
     def _flush(self):
@@ -54,6 +55,10 @@ class GradReducer:
             self._flush()
 
     def wait(self):
+        if self._lora is not None and self.world > 1:
+            op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
+            buf = self._lora.flat_grad
+            self._pending.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf))
         self._flush()
         for w, buf in self._pending:
             w.wait()

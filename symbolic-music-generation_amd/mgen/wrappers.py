@@ -116,8 +116,7 @@ class MidiQwen(_Wrapper):
 
 class MidiAria(_Wrapper):
     """The reference fine-tunes a remote-code Llama-style checkpoint (loubb/aria-medium-base) that cannot be fetched
-    here; this wrapper builds a Llama-architecture network of that size class with random weights. LoRA (`to_lora`)
-    is not built."""
+    here; this wrapper builds a Llama-architecture network of that size class with random weights."""
     lr_default, warmup_default = 1e-5, 100
 
     def __init__(self, tokenizer, dataloader, lr=None, warmup_steps=None, device="cuda", config: Optional[LMConfig] = None,
@@ -126,7 +125,10 @@ class MidiAria(_Wrapper):
         self.model = MidiLM(config or aria_style_llama(), device=device, seed=seed)
 
     def to_lora(self):
-        raise NotImplementedError("LoRA adapters are outside the built path")
+        """/root/reference/src/model/model.py:251-271: freeze the base, rank-32 adapters (alpha 64) on the fused QKV,
+        attention output, gate, up and down projections. Call it before configure_optimizers(): the optimizer then
+        covers the adapters only. (The reference's adapter dropout of 0.05 is not applied.)"""
+        return self.model.to_lora(r=32, lora_alpha=64)
 
 
 class MidiGPT2(_Wrapper):

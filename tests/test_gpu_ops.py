@@ -92,6 +92,22 @@ def test_gemm_weight_gradient_split_k(ops, M, N, K):
     assert rel(c, prev + 2 * ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,ldc", [(300, 200, 32, 200), (1000, 512, 32, 1024), (257, 72, 64, 76)])
+def test_gemm_accumulate_into_bf16(ops, M, N, K, ldc):
+    """out_mode 6: C (bf16) = bf16(C + A B^T), the low-rank adapter epilogue; vector path (ldc % 8 == 0) and the
+    element-wise one, C a column block of a wider matrix."""
+    g = torch.Generator().manual_seed(M + N)
+    A = bf(torch.randn(M, K, generator=g))
+    B = bf(torch.randn(N, K, generator=g) * 0.3)
+    C0 = bf(torch.randn(M, ldc, generator=g))
+    c = C0.clone().to(dev())
+    ops.gemm(A.to(dev()), B.to(dev()), c, M, N, K, K, K, ldc, out_mode=ops.OUT_BF16_ACC)
+    want = C0.float().clone()
+    want[:, :N] += A.float() @ B.float().t()
+    assert rel(c[:, :N].float(), want[:, :N]) < 1e-2
+    assert torch.equal(c[:, N:].cpu(), C0[:, N:]), "wrote outside the N columns"
+
+
 def test_gemm_exact_identity_asymmetric(ops):
     """A = I against an asymmetric integer B: catches swapped rows/columns and a wrong k order exactly."""
     n = 128
