@@ -71,7 +71,8 @@ def test_gemm_layouts(ops, ta, tb, M, N, K):
     assert rel(out, res.cpu() + bf(ref).float()) < 1e-2
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 8192), (512, 1024, 4096 + 64), (100, 72, 5000)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 8192), (512, 1024, 4096 + 64), (100, 72, 5000),
+                                   (520, 1000, 8192 + 64)])   # the last: 128x256 tiles with split-K atomics
 def test_gemm_weight_gradient_split_k(ops, M, N, K):
     """dW[M,N] += dY[K,M]^T X[K,N] with few output tiles and a long reduction: the split-K (atomic) path."""
     g = torch.Generator().manual_seed(K)
