@@ -123,6 +123,34 @@ int mgen_attn_fwd(const void* q, const void* k, const void* v, void* out, float*
 int mgen_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                   float* delta, void* dq, void* dk, void* dv, long sq, long sk, long sv, long so, long sdo, long sdq,
                   long sdk, long sdv, int B, int S, int H, int KVH, int head_dim, float scale, mgen_stream_t stream);
+/* The same two with dropout on the attention probabilities — GPT2Attention's attn_dropout, TF
+ * models/gpt2/modeling_gpt2.py (eager_attention_forward: softmax, dropout, then the product with v; attn_pdrop 0.1,
+ * configuration_gpt2.py:87). Probability (b*H + h, q, key) is kept iff fmix32(rowkey ^ key) >= floor(p * 2^32) with
+ * rowkey = fmix32(((b*H + h) * 0x9E3779B1 + q) ^ low32(key64)) + high32(key64) and fmix32 the 32-bit murmur3
+ * finaliser; kept probabilities are scaled by 1/(1-p), the softmax normaliser counts all of them. The backward call
+ * takes the p and key of its forward call (the mask is recomputed, never stored). p in [0, 1). */
+int mgen_attn_fwd_dropout(const void* q, const void* k, const void* v, void* out, float* lse, long sq, long sk, long sv,
+                          long so, int B, int S, int H, int KVH, int head_dim, float scale, float p,
+                          unsigned long long key, mgen_stream_t stream);
+int mgen_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                          const float* lse, float* delta, void* dq, void* dk, void* dv, long sq, long sk, long sv,
+                          long so, long sdo, long sdq, long sdk, long sdv, int B, int S, int H, int KVH, int head_dim,
+                          float scale, float p, unsigned long long key, mgen_stream_t stream);
+
+/* ---- element-wise dropout ------------------------------------------------------------------------------------
+ * torch.nn.Dropout in training mode as GPT-2 uses it (TF models/gpt2/modeling_gpt2.py: `drop` on the summed
+ * embeddings, `resid_dropout` after attn.c_proj, `dropout` after mlp.c_proj; configuration_gpt2.py:85-86) and the
+ * adapters' lora_dropout (reference src/model/model.py:255). Element i is kept iff
+ * fmix32(fmix32(low32(i) ^ low32(key)) + high32(key) + high32(i) * 0x9E3779B1) >= floor(p * 2^32); kept elements are
+ * scaled by 1/(1-p) and rounded to the tensor's type. y may alias x; the gradient is the same call on the upstream
+ * gradient. x, y: n contiguous bf16 (is_bf16) or fp32 elements, 16-byte aligned. */
+int mgen_dropout(const void* x, void* y, long n, int is_bf16, float p, unsigned long long key, mgen_stream_t stream);
+/* y += dropout(x), each term rounded to the tensors' type (a dropped branch's gradient joining the others'). */
+int mgen_dropout_add(const void* x, void* y, long n, int is_bf16, float p, unsigned long long key,
+                     mgen_stream_t stream);
+/* out = resid + float(bf16(dropout(y))): the residual add after a dropped bf16 projection (y bf16, resid/out fp32). */
+int mgen_dropout_resid(const void* y, const float* resid, float* out, long n, float p, unsigned long long key,
+                       mgen_stream_t stream);
 
 /* ---- SwiGLU gate ---------------------------------------------------------------------------------------------
  * act = silu(gate) * up with gu = [gate | up] per row ([T][2I] bf16) — Qwen3MLP.forward,

@@ -128,9 +128,11 @@ def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.T
 
 
 def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
-                     key_padding_mask: Optional[torch.Tensor] = None, q_offset: int = 0) -> torch.Tensor:
+                     key_padding_mask: Optional[torch.Tensor] = None, q_offset: int = 0,
+                     drop_keep: Optional[torch.Tensor] = None, drop_p: float = 0.0) -> torch.Tensor:
     """q [B,H,Sq,Dh], k/v [B,KVH,Sk,Dh] -> [B,Sq,H*Dh]. Softmax in fp32. Query i sits at absolute position
-    q_offset+i and may see keys 0..q_offset+i. key_padding_mask [B,Sk] (1 = real token)."""
+    q_offset+i and may see keys 0..q_offset+i. key_padding_mask [B,Sk] (1 = real token). drop_keep (bool
+    [B,H,Sq,Sk]) with drop_p: dropout on the probabilities after the softmax (GPT-2's attn_dropout)."""
     B, H, Sq, Dh = q.shape
     KVH, Sk = k.shape[1], k.shape[2]
     if KVH != H:
@@ -145,6 +147,8 @@ def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: f
         allowed = allowed & key_padding_mask.bool()[:, None, None, :]
     w = w.masked_fill(~allowed, torch.finfo(w.dtype).min)
     w = F.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    if drop_keep is not None:
+        w = w * drop_keep.to(w.dtype) * (1.0 / (1.0 - drop_p))
     o = torch.matmul(w, v)
     return o.transpose(1, 2).reshape(B, Sq, H * Dh)
 

@@ -32,6 +32,7 @@ import torch
 import torch.nn.functional as F
 
 from .ref_cpu import LMConfig, KVCache, causal_attention, causal_lm_loss, _bf, warp_logits, sample_with_noise
+from . import ref_dropout as RD
 
 LN_EPS = 1e-5
 
@@ -68,7 +69,8 @@ def gelu_new(x):
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
-def block(h, p, pre, cfg: LMConfig, mode, kpm, cache: Optional[KVCache], layer: int):
+def block(h, p, pre, cfg: LMConfig, mode, kpm, cache: Optional[KVCache], layer: int, drop=None):
+    """drop: an oracle.ref_dropout.DropPlan (training-mode forward with its masks) or None (eval arithmetic)."""
     B, S, d = h.shape
     H = cfg.num_attention_heads
     Dh = d // H
@@ -82,18 +84,28 @@ def block(h, p, pre, cfg: LMConfig, mode, kpm, cache: Optional[KVCache], layer: 
             k = torch.cat([cache.k[layer], k], dim=2)
             v = torch.cat([cache.v[layer], v], dim=2)
         cache.k[layer], cache.v[layer] = k, v
+    keep, ap = None, 0.0
+    if drop is not None and drop.attn_p > 0:
+        keep, ap = RD.keep_attn(drop.key(3 * layer + 1), B, H, S, drop.attn_p), drop.attn_p
     if mode == "bf16":
-        a = _bf(causal_attention(q.float(), k.float(), v.float(), Dh ** -0.5, kpm, q_offset))
+        a = _bf(causal_attention(q.float(), k.float(), v.float(), Dh ** -0.5, kpm, q_offset, keep, ap))
     else:
-        a = causal_attention(q, k, v, Dh ** -0.5, kpm, q_offset)
-    h = h + conv1d(a, p[pre + "attn.c_proj.weight"], p[pre + "attn.c_proj.bias"], mode)
+        a = causal_attention(q, k, v, Dh ** -0.5, kpm, q_offset, keep, ap)
+
+    def resid_drop(y, site):
+        if drop is None or drop.resid_p == 0:
+            return y
+        return RD.apply(y, RD.keep_flat(drop.key(site), y.numel(), drop.resid_p), drop.resid_p)
+
+    h = h + resid_drop(conv1d(a, p[pre + "attn.c_proj.weight"], p[pre + "attn.c_proj.bias"], mode), 3 * layer + 2)
     x = F.layer_norm(h, (d,), p[pre + "ln_2.weight"], p[pre + "ln_2.bias"], LN_EPS)
     f = conv1d(x, p[pre + "mlp.c_fc.weight"], p[pre + "mlp.c_fc.bias"], mode)
     act = gelu_new(f.float()) if mode == "bf16" else gelu_new(f)
-    return h + conv1d(act, p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"], mode)
+    return h + resid_drop(conv1d(act, p[pre + "mlp.c_proj.weight"], p[pre + "mlp.c_proj.bias"], mode), 3 * layer + 3)
 
 
-def forward_hidden(p, cfg: LMConfig, input_ids, attention_mask=None, mode="fp32", cache: Optional[KVCache] = None):
+def forward_hidden(p, cfg: LMConfig, input_ids, attention_mask=None, mode="fp32", cache: Optional[KVCache] = None,
+                   drop=None):
     B, S = input_ids.shape
     past = cache.length() if cache is not None else 0
     if cache is not None and not cache.k:
@@ -101,23 +113,25 @@ def forward_hidden(p, cfg: LMConfig, input_ids, attention_mask=None, mode="fp32"
         cache.v = [None] * cfg.num_hidden_layers
     pos = torch.arange(past, past + S)
     h = F.embedding(input_ids, p["transformer.wte.weight"]) + p["transformer.wpe.weight"][pos][None]
+    if drop is not None and drop.embd_p > 0:
+        h = RD.apply(h, RD.keep_flat(drop.key(0), h.numel(), drop.embd_p), drop.embd_p)
     kpm = attention_mask if (attention_mask is not None and not bool(attention_mask.bool().all())) else None
     for l in range(cfg.num_hidden_layers):
-        h = block(h, p, f"transformer.h.{l}.", cfg, mode, kpm, cache, l)
+        h = block(h, p, f"transformer.h.{l}.", cfg, mode, kpm, cache, l, drop)
     return F.layer_norm(h, (cfg.hidden_size,), p["transformer.ln_f.weight"], p["transformer.ln_f.bias"], LN_EPS)
 
 
-def forward(p, cfg: LMConfig, input_ids, attention_mask=None, labels=None, mode="fp32", cache=None):
-    hN = forward_hidden(p, cfg, input_ids, attention_mask, mode, cache)
+def forward(p, cfg: LMConfig, input_ids, attention_mask=None, labels=None, mode="fp32", cache=None, drop=None):
+    hN = forward_hidden(p, cfg, input_ids, attention_mask, mode, cache, drop)
     W = p["transformer.wte.weight"]
     logits = F.linear(_bf(hN), _bf(W)) if mode == "bf16" else F.linear(hN, W)
     loss = causal_lm_loss(logits, labels) if labels is not None else None
     return loss, logits
 
 
-def loss_and_grads(p, cfg, input_ids, attention_mask, labels, mode="fp32"):
+def loss_and_grads(p, cfg, input_ids, attention_mask, labels, mode="fp32", drop=None):
     q = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
-    loss, _ = forward(q, cfg, input_ids, attention_mask, labels, mode)
+    loss, _ = forward(q, cfg, input_ids, attention_mask, labels, mode, drop=drop)
     loss.backward()
     return loss.detach(), {k: v.grad for k, v in q.items()}
 

@@ -35,6 +35,11 @@ struct AttnArgs {
     int B, S, H, KVH;
     float scale;
     int gx, gy, gz;  // logical grid: row blocks, head (pair) index, batch; launched as one dimension
+    // dropout on the attention probabilities (kernels instantiated with DROP): element (b*H + h, q, key) is kept iff
+    // drop_fmix32(drop_rowkey(drop_key, b*H + h, q) ^ key) >= drop_thresh; kept probabilities count 1 / (1 - p)
+    unsigned long long drop_key;
+    unsigned drop_thresh;
+    float drop_inv_keep;
 };
 
 // Logical workgroup coordinates from the 1-D launch index. Hardware deals consecutive workgroups round-robin to the
@@ -136,7 +141,7 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&acc)[DB], bf16* __re
 // ===================================================================================================
 // forward
 // ===================================================================================================
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
@@ -164,6 +169,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     float m = NEG_BIG, l = 0.f;
     const float sl2 = a.scale * LOG2E;
     const int my_q = qw0 + (lane & 31);
+    // key = kv0 + 32t + 4*(lane>>5) + c_r with c_r = (r&3) + 8*(r>>2): the register part occupies bits the rest leaves
+    // free, so the hash input is (rowkey ^ lane part) ^ c_r
+    unsigned rk = 0;
+    if constexpr (DROP) rk = drop_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)my_q) ^ (unsigned)(4 * (lane >> 5));
 
     const int last_key = min(q0 + G::ROWS - 1, S - 1);
     const int ntiles = last_key / 64 + 1;
@@ -226,9 +235,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float p = fast_exp2(__builtin_fmaf(s[t][r], sl2, nm));
+                        float p = fast_exp2(__builtin_fmaf(s[t][r], sl2, nm));
+                        psum += p;   // the softmax normaliser counts every visible key, dropped or not
+                        if constexpr (DROP) {
+                            const unsigned hsh = drop_fmix32(rk ^ (unsigned)(kv0 + 32 * t) ^ (unsigned)((r & 3) + 8 * (r >> 2)));
+                            if (hsh < a.drop_thresh) p = 0.f;
+                        }
                         s[t][r] = p;
-                        psum += p;
                     }
                 l += psum;
                 bf16x8 pf[2][2];
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 
     const float lt = l + __shfl_xor(l, 32, 64);
     if (my_q < S) {
-        const float inv = 1.f / lt;
+        const float inv = (DROP ? a.drop_inv_keep : 1.f) / lt;
         store_rows_T<G::DB>(o, a.Out + (tok0 + my_q) * a.so + (long)h * HD, inv, lane);
         if (lane < 32 && a.LSE) a.LSE[((long)b * a.H + h) * S + my_q] = (m * sl2 + __log2f(lt)) * LN2;
     }
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
 // ===================================================================================================
 // backward, part 1: dQ. Same work decomposition as the forward.
 // ===================================================================================================
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -319,6 +332,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const float lse2 = a.LSE[((long)b * a.H + h) * S + cq] * LOG2E;
     const float delta = a.Delta[((long)b * a.H + h) * S + cq];
     const float sl2 = a.scale * LOG2E;
+    unsigned rk = 0;   // as in the forward kernel
+    if constexpr (DROP) rk = drop_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)my_q) ^ (unsigned)(4 * (lane >> 5));
 
     f32x16 dq[G::DB];
 #pragma unroll
@@ -365,7 +380,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     float p = fast_exp2(__builtin_fmaf(s[r], sl2, -lse2));
                     if ((r & 3) + 8 * (r >> 2) > thr) p = 0.f;
-                    s[r] = p * (dp[r] - delta);  // dS^T[key][q]
+                    float dpv = dp[r];
+                    if constexpr (DROP) {
+                        const unsigned hsh = drop_fmix32(rk ^ (unsigned)(kv0 + 32 * t) ^ (unsigned)((r & 3) + 8 * (r >> 2)));
+                        dpv = hsh < a.drop_thresh ? 0.f : dpv * a.drop_inv_keep;
+                    }
+                    s[r] = p * (dpv - delta);  // dS^T[key][q]
                 }
                 const bf16x8 f0 = acc_to_frag<0>(s), f1 = acc_to_frag<1>(s);
                 // dQ^T[d][q] += K^T[d][key] * dS^T[key][q]
@@ -387,9 +407,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
 // (head_dim 64); loops over the query heads of the group and over the query tiles at or after the block's first
 // key. LDS per buffer: Q tile | dO tile | lse2[2][64] | delta[2][64]
 // ===================================================================================================
-constexpr int DKV_BUF = 2 * TILE + 1024;
+// (+ rowkey[2][64] of the dropout hash, + padding to a multiple of 1 KiB)
+constexpr int DKV_BUF = 2 * TILE + 2048;
 
-template <int HD>
+template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -424,6 +445,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int nsteps = per_head * group;
 
     float s_lse = 0.f, s_delta = 0.f;
+    unsigned s_rk = 0;
 
     auto issue = [&](int step, int buf) {
         // first query head of the tile row for this step
@@ -437,6 +459,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
             const long o = ((long)b * a.H + hq0 + (tid >> 6)) * S + q;
             s_lse = a.LSE[o] * LOG2E;
             s_delta = a.Delta[o];
+            if constexpr (DROP) s_rk = drop_rowkey(a.drop_key, (unsigned)(b * a.H + hq0 + (tid >> 6)), (unsigned)q);
         }
     };
     auto commit = [&](int buf) {
@@ -444,6 +467,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (tid < 64 * G::HPB) {
             reinterpret_cast<float*>(base + 2 * TILE)[tid] = s_lse;
             reinterpret_cast<float*>(base + 2 * TILE + 512)[tid] = s_delta;
+            if constexpr (DROP) reinterpret_cast<unsigned*>(base + 2 * TILE + 1024)[tid] = s_rk;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
@@ -466,6 +490,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
         const char* dOt = Qt + TILE;
         const float* lse_s = reinterpret_cast<const float*>(Qt + 2 * TILE) + 64 * sub;
         const float* del_s = reinterpret_cast<const float*>(Qt + 2 * TILE + 512) + 64 * sub;
+        const unsigned* rk_s = reinterpret_cast<const unsigned*>(Qt + 2 * TILE + 1024) + 64 * sub;
         // all four score / dP chains first: the matrix cores then work through the second half's chains while the
         // vector ALU does the first half's exponentials
         f32x16 s[2], dp[2];
@@ -499,6 +524,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
                 const int qr = 32 * u + 8 * g4 + 4 * (lane >> 5);
                 const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + qr);
                 const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + qr);
+                u32x4 rv = {0u, 0u, 0u, 0u};
+                if constexpr (DROP) rv = *reinterpret_cast<const u32x4*>(rk_s + qr);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
@@ -507,8 +534,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
                         const int q = qt0 + qr + e;
                         if (my_k > q || q >= S) p = 0.f;
                     }
-                    s[u][r] = p;
-                    ds[r] = p * (dp[u][r] - dl[e]);
+                    if constexpr (DROP) {   // dV sees the dropped probabilities, dS the dropped dP
+                        const bool keep = drop_fmix32(rv[e] ^ (unsigned)my_k) >= a.drop_thresh;
+                        s[u][r] = keep ? p : 0.f;
+                        ds[r] = p * ((keep ? dp[u][r] * a.drop_inv_keep : 0.f) - dl[e]);
+                    } else {
+                        s[u][r] = p;
+                        ds[r] = p * (dp[u][r] - dl[e]);
+                    }
                 }
             }
             const bf16x8 p0 = acc_to_frag<0>(s[u]), p1 = acc_to_frag<1>(s[u]);
@@ -538,7 +571,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
     if (my_k < S) {
         store_rows_T<G::DB>(dk, a.dK + (tok0 + my_k) * a.sdk + (long)kvh * HD, a.scale, lane);
-        store_rows_T<G::DB>(dv, a.dV + (tok0 + my_k) * a.sdv + (long)kvh * HD, 1.f, lane);
+        store_rows_T<G::DB>(dv, a.dV + (tok0 + my_k) * a.sdv + (long)kvh * HD, DROP ? a.drop_inv_keep : 1.f, lane);
     }
 }
 
@@ -562,45 +595,58 @@ int set_lds(K kernel, int bytes, const char* who) {
     return MGEN_OK;
 }
 
-}  // namespace
+int set_drop(AttnArgs& a, float p, unsigned long long key, const char* who) {
+    MGEN_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout probability must be in [0, 1) (got %g)", who, p);
+    a.drop_key = key;
+    a.drop_thresh = drop_threshold(p);
+    a.drop_inv_keep = 1.f / (1.f - p);
+    return MGEN_OK;
+}
 
-extern "C" int mgen_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, long sq, long sk,
-                             long sv, long so, int B, int S, int H, int KVH, int head_dim, float scale,
-                             hipStream_t stream) {
-    MGEN_REQUIRE(q && k && v && out, "mgen_attn_fwd: null pointer");
+int attn_fwd_impl(const void* q, const void* k, const void* v, void* out, float* lse, long sq, long sk, long sv, long so,
+                  int B, int S, int H, int KVH, int head_dim, float scale, float p, unsigned long long key,
+                  hipStream_t stream, const char* who) {
+    MGEN_REQUIRE(q && k && v && out, "%s: null pointer", who);
     AttnArgs a = {};
     a.Q = (const bf16*)q; a.K = (const bf16*)k; a.V = (const bf16*)v; a.Out = (bf16*)out; a.LSE = lse;
     a.sq = sq; a.sk = sk; a.sv = sv; a.so = so; a.B = B; a.S = S; a.H = H; a.KVH = KVH; a.scale = scale;
-    if (int e = check_common(a, head_dim, "mgen_attn_fwd")) return e;
-    MGEN_REQUIRE(so % 4 == 0, "mgen_attn_fwd: output token stride must be a multiple of 4");
+    if (int e = check_common(a, head_dim, who)) return e;
+    if (int e = set_drop(a, p, key, who)) return e;
+    MGEN_REQUIRE(so % 4 == 0, "%s: output token stride must be a multiple of 4", who);
     const dim3 block(256);
     a.gx = head_dim == 128 ? (S + 127) / 128 : (S + 63) / 64;
     a.gy = head_dim == 128 ? H : H / 2;
     a.gz = B;
-    MGEN_REQUIRE((long)a.gx * a.gy * a.gz < (1L << 31), "mgen_attn_fwd: grid too large");
+    MGEN_REQUIRE((long)a.gx * a.gy * a.gz < (1L << 31), "%s: grid too large", who);
     const dim3 grid((unsigned)(a.gx * a.gy * a.gz));
-    if (head_dim == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, block, 4 * TILE, stream, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, block, 4 * TILE, stream, a);
-    return mgen_check_launch("mgen_attn_fwd");
+    const bool drop = p > 0.f;
+    if (head_dim == 128 && !drop) hipLaunchKernelGGL((attn_fwd_kernel<128, false>), grid, block, 4 * TILE, stream, a);
+    else if (head_dim == 128) hipLaunchKernelGGL((attn_fwd_kernel<128, true>), grid, block, 4 * TILE, stream, a);
+    else if (!drop) hipLaunchKernelGGL((attn_fwd_kernel<64, false>), grid, block, 4 * TILE, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, block, 4 * TILE, stream, a);
+    return mgen_check_launch(who);
 }
 
-extern "C" int mgen_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
-                             const float* lse, float* delta, void* dq, void* dk, void* dv, long sq, long sk, long sv,
-                             long so, long sdo, long sdq, long sdk, long sdv, int B, int S, int H, int KVH,
-                             int head_dim, float scale, hipStream_t stream) {
-    MGEN_REQUIRE(q && k && v && out && dout && lse && delta && dq && dk && dv, "mgen_attn_bwd: null pointer");
+int attn_bwd_impl(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                  float* delta, void* dq, void* dk, void* dv, long sq, long sk, long sv, long so, long sdo, long sdq,
+                  long sdk, long sdv, int B, int S, int H, int KVH, int head_dim, float scale, float p,
+                  unsigned long long key, hipStream_t stream, const char* who) {
+    MGEN_REQUIRE(q && k && v && out && dout && lse && delta && dq && dk && dv, "%s: null pointer", who);
     AttnArgs a = {};
     a.Q = (const bf16*)q; a.K = (const bf16*)k; a.V = (const bf16*)v; a.O = (const bf16*)out; a.dO = (const bf16*)dout;
     a.dQ = (bf16*)dq; a.dK = (bf16*)dk; a.dV = (bf16*)dv; a.LSE = (float*)lse; a.Delta = delta;
     a.sq = sq; a.sk = sk; a.sv = sv; a.so = so; a.sdo = sdo; a.sdq = sdq; a.sdk = sdk; a.sdv = sdv;
     a.B = B; a.S = S; a.H = H; a.KVH = KVH; a.scale = scale;
-    if (int e = check_common(a, head_dim, "mgen_attn_bwd")) return e;
+    if (int e = check_common(a, head_dim, who)) return e;
+    if (int e = set_drop(a, p, key, who)) return e;
     MGEN_REQUIRE(so % 8 == 0 && sdo % 8 == 0 && sdq % 4 == 0 && sdk % 4 == 0 && sdv % 4 == 0,
-                 "mgen_attn_bwd: bad token stride alignment");
+                 "%s: bad token stride alignment", who);
     static bool attr_set = false;
     if (!attr_set) {
-        if (int e = set_lds(attn_bwd_dkv_kernel<128>, 2 * DKV_BUF, "mgen_attn_bwd")) return e;
-        if (int e = set_lds(attn_bwd_dkv_kernel<64>, 2 * DKV_BUF, "mgen_attn_bwd")) return e;
+        if (int e = set_lds(attn_bwd_dkv_kernel<128, false>, 2 * DKV_BUF, who)) return e;
+        if (int e = set_lds(attn_bwd_dkv_kernel<64, false>, 2 * DKV_BUF, who)) return e;
+        if (int e = set_lds(attn_bwd_dkv_kernel<128, true>, 2 * DKV_BUF, who)) return e;
+        if (int e = set_lds(attn_bwd_dkv_kernel<64, true>, 2 * DKV_BUF, who)) return e;
         attr_set = true;
     }
     const long nrows = (long)B * S * H;
@@ -609,19 +655,66 @@ extern "C" int mgen_attn_bwd(const void* q, const void* k, const void* v, const 
     if (nb > 8192) nb = 8192;
     const dim3 block(256);
     const int nrb = head_dim == 128 ? (S + 127) / 128 : (S + 63) / 64;   // row blocks
-    MGEN_REQUIRE((long)nrb * H * B < (1L << 31), "mgen_attn_bwd: grid too large");
+    MGEN_REQUIRE((long)nrb * H * B < (1L << 31), "%s: grid too large", who);
     AttnArgs akv = a, aq = a;   // the two kernels walk different logical grids
     akv.gx = nrb; akv.gy = head_dim == 128 ? KVH : KVH / 2; akv.gz = B;
     aq.gx = nrb; aq.gy = head_dim == 128 ? H : H / 2; aq.gz = B;
     const dim3 gkv((unsigned)(akv.gx * akv.gy * akv.gz)), gq((unsigned)(aq.gx * aq.gy * aq.gz));
+    const bool drop = p > 0.f;
+    // delta = rowsum(dO * O) holds with dropout too: sum_k P dP = sum_k P~ dP~ = dO . O
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)nb), block, 0, stream, a.O, a.dO, so, sdo, delta, B, S, H);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, gkv, block, 2 * DKV_BUF, stream, akv);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, block, 4 * TILE, stream, aq);
+        if (!drop) {
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, false>), gkv, block, 2 * DKV_BUF, stream, akv);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<128, false>), gq, block, 4 * TILE, stream, aq);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, true>), gkv, block, 2 * DKV_BUF, stream, akv);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<128, true>), gq, block, 4 * TILE, stream, aq);
+        }
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)nb), block, 0, stream, a.O, a.dO, so, sdo, delta, B, S, H);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, gkv, block, 2 * DKV_BUF, stream, akv);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, block, 4 * TILE, stream, aq);
+        if (!drop) {
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, false>), gkv, block, 2 * DKV_BUF, stream, akv);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<64, false>), gq, block, 4 * TILE, stream, aq);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, true>), gkv, block, 2 * DKV_BUF, stream, akv);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, block, 4 * TILE, stream, aq);
+        }
     }
-    return mgen_check_launch("mgen_attn_bwd");
+    return mgen_check_launch(who);
+}
+
+}  // namespace
+
+extern "C" int mgen_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, long sq, long sk,
+                             long sv, long so, int B, int S, int H, int KVH, int head_dim, float scale,
+                             hipStream_t stream) {
+    return attn_fwd_impl(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, head_dim, scale, 0.f, 0ull, stream,
+                         "mgen_attn_fwd");
+}
+
+extern "C" int mgen_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                             const float* lse, float* delta, void* dq, void* dk, void* dv, long sq, long sk, long sv,
+                             long so, long sdo, long sdq, long sdk, long sdv, int B, int S, int H, int KVH,
+                             int head_dim, float scale, hipStream_t stream) {
+    return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, sq, sk, sv, so, sdo, sdq, sdk, sdv, B, S, H, KVH,
+                         head_dim, scale, 0.f, 0ull, stream, "mgen_attn_bwd");
+}
+
+// The same two with dropout on the attention probabilities (probability p in [0, 1), mask from `key`; see AttnArgs).
+// The backward call must get the p and key of its forward call.
+extern "C" int mgen_attn_fwd_dropout(const void* q, const void* k, const void* v, void* out, float* lse, long sq,
+                                     long sk, long sv, long so, int B, int S, int H, int KVH, int head_dim,
+                                     float scale, float p, unsigned long long key, hipStream_t stream) {
+    return attn_fwd_impl(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, head_dim, scale, p, key, stream,
+                         "mgen_attn_fwd_dropout");
+}
+
+extern "C" int mgen_attn_bwd_dropout(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                     const float* lse, float* delta, void* dq, void* dk, void* dv, long sq, long sk,
+                                     long sv, long so, long sdo, long sdq, long sdk, long sdv, int B, int S, int H,
+                                     int KVH, int head_dim, float scale, float p, unsigned long long key,
+                                     hipStream_t stream) {
+    return attn_bwd_impl(q, k, v, out, dout, lse, delta, dq, dk, dv, sq, sk, sv, so, sdo, sdq, sdk, sdv, B, S, H, KVH,
+                         head_dim, scale, p, key, stream, "mgen_attn_bwd_dropout");
 }

@@ -73,6 +73,32 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Dropout masks: a stateless 32-bit hash of (key, element index) compared with a threshold; an element is KEPT
+// iff hash >= thresh, thresh = floor(p * 2^32). Backward passes recompute the mask from the same key, nothing is
+// stored. Two index forms: flat (any tensor, 64-bit element index) and attention (batch*heads + head, query, key).
+// ---------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ unsigned drop_fmix32(unsigned h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ unsigned drop_hash_flat(unsigned long long key, unsigned long long idx) {
+    const unsigned r = drop_fmix32((unsigned)idx ^ (unsigned)key);
+    return drop_fmix32(r + (unsigned)(key >> 32) + (unsigned)(idx >> 32) * 0x9E3779B1u);
+}
+// per (head, query) part of the attention hash; the element hash is drop_fmix32(rowkey ^ key_index)
+__host__ __device__ __forceinline__ unsigned drop_rowkey(unsigned long long key, unsigned bh, unsigned q) {
+    return drop_fmix32((bh * 0x9E3779B1u + q) ^ (unsigned)key) + (unsigned)(key >> 32);
+}
+__host__ __forceinline__ unsigned drop_threshold(float p) {
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // bf16 helpers
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

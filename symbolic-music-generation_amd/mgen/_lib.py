@@ -30,6 +30,11 @@ SIGNATURES = {
     "mgen_pos4d_next": [P, L, P, L, P, L, I, P],
     "mgen_attn_fwd": [P, P, P, P, P, L, L, L, L, I, I, I, I, I, F, P],
     "mgen_attn_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, P],
+    "mgen_attn_fwd_dropout": [P, P, P, P, P, L, L, L, L, I, I, I, I, I, F, F, U64, P],
+    "mgen_attn_bwd_dropout": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, F, U64, P],
+    "mgen_dropout": [P, P, L, I, F, U64, P],
+    "mgen_dropout_add": [P, P, L, I, F, U64, P],
+    "mgen_dropout_resid": [P, P, P, L, F, U64, P],
     "mgen_swiglu_fwd": [P, P, L, I, I, P],
     "mgen_swiglu_bwd": [P, P, P, L, I, P],
     "mgen_embedding_fwd": [P, P, P, L, I, L, P, P],

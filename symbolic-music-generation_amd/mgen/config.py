@@ -35,6 +35,11 @@ class LMConfig:
     # with biased Conv1D layers (mgen.gpt2.MidiGPT2LM)
     arch: str = "llama"
     layer_norm_eps: float = 1e-5
+    # GPT-2 dropout probabilities (training mode only): summed embeddings, both residual projections, attention
+    # probabilities. transformers' GPT2Config defaults are 0.1 each and the reference does not override them.
+    embd_pdrop: float = 0.0
+    resid_pdrop: float = 0.0
+    attn_pdrop: float = 0.0
     rope4d_theta: float = 10000.0     # fixed in the reference (:510), independent of rope_theta
     rope4d_nope: int = 4              # zero frequencies ("NoPE" pairs) at the end of each axis' block (:522-525)
 
@@ -57,12 +62,13 @@ def pos4d_decoder() -> LMConfig:
     return LMConfig(vocab_size=1, tie_word_embeddings=False, pos4d=True)
 
 
-def gpt2_decoder(vocab_size: int = 30000, n_positions: int = 4096) -> LMConfig:
+def gpt2_decoder(vocab_size: int = 30000, n_positions: int = 4096, pdrop: float = 0.1) -> LMConfig:
     """The reference's GPT-2 variant (MidiGPT2, src/model/model.py:54-64): n_embd 512, 6 layers, 8 heads; the
-    vocabulary is the trained tokenizer's (30 000), n_positions = CONTEXT_SIZE = 4096 (src/utils.py:4)."""
+    vocabulary is the trained tokenizer's (30 000), n_positions = CONTEXT_SIZE = 4096 (src/utils.py:4); dropout 0.1
+    everywhere (the GPT2Config defaults, transformers models/gpt2/configuration_gpt2.py:85-87)."""
     return LMConfig(arch="gpt2", vocab_size=vocab_size, hidden_size=512, intermediate_size=2048, num_hidden_layers=6,
                     num_attention_heads=8, num_key_value_heads=8, head_dim=64, max_position_embeddings=n_positions,
-                    tie_word_embeddings=True, qk_norm=False)
+                    tie_word_embeddings=True, qk_norm=False, embd_pdrop=pdrop, resid_pdrop=pdrop, attn_pdrop=pdrop)
 
 
 def aria_style_llama() -> LMConfig:

@@ -7,8 +7,11 @@ weights are stored [in, out].
 
 Block arithmetic (transformers models/gpt2/modeling_gpt2.py, GPT2Block.forward): pre-LayerNorm residual blocks,
 fused c_attn producing q | k | v, causal attention over 64-wide heads scaled by 1/sqrt(64), c_proj, gelu_new MLP,
-learned absolute positions, head tied to wte. Dropout is not applied (the kernels implement the p = 0 / eval
-arithmetic; the reference's config default of 0.1 makes its training runs stochastic).
+learned absolute positions, head tied to wte. In training mode (`model.train()`, the default) with non-zero
+`embd_pdrop` / `resid_pdrop` / `attn_pdrop` the three dropouts of GPT2Model are applied: on the summed embeddings, on
+the output of both residual projections, and on the attention probabilities inside the attention kernels. Masks
+are a hash of (key, element index); every dropout site of every forward gets its own key from `dropout_seed` and a
+running counter, the backward pass recomputes the masks from the keys (nothing is stored).
 """
 from __future__ import annotations
 
@@ -52,6 +55,20 @@ class MidiGPT2LM(MidiLM):
                 cfg.num_key_value_heads != cfg.num_attention_heads or not cfg.tie_word_embeddings:
             raise ValueError("GPT-2: hidden = heads * head_dim, no grouped keys, tied head")
         super().__init__(cfg, device=device, seed=seed)
+        self.dropout_seed = int(seed or 0)     # give every data-parallel rank its own
+        self._dropout_calls = 0                # training-mode forwards so far
+
+    def _drop_keys(self, cache, pos):
+        """Keys of this forward's dropout sites, or None when dropout is off (eval mode, decoding, all p = 0).
+        Site 0 = embeddings, then per layer: attention probabilities, attention projection, MLP projection."""
+        cfg = self.cfg
+        if not self.training or cache is not None or pos is not None or \
+                (cfg.embd_pdrop == 0 and cfg.resid_pdrop == 0 and cfg.attn_pdrop == 0):
+            return None
+        n = 3 * cfg.num_hidden_layers + 1
+        base = self._dropout_calls * n
+        self._dropout_calls += 1
+        return [ops.dropout_key(self.dropout_seed, base + i) for i in range(n)]
 
     # ---- parameter store -----------------------------------------------------------------------------------
     def _param_layout(self):
@@ -113,6 +130,22 @@ class MidiGPT2LM(MidiLM):
         h = torch.empty(T, d, dtype=f32, device=dev)
         ops.embed_pos_fwd(input_ids, self.transformer.wte.weight, self.transformer.wpe.weight, pos, h, S,
                           self._err_flag)
+        keys = self._drop_keys(cache, pos)
+        p_e, p_r, p_a = (cfg.embd_pdrop, cfg.resid_pdrop, cfg.attn_pdrop) if keys else (0.0, 0.0, 0.0)
+        if p_e > 0:
+            ops.dropout(h, h, p_e, keys[0])
+
+        def proj_resid(x, w, b, resid, key):
+            """resid + bf16(x w + b), the projection output dropped first when resid_pdrop is on"""
+            out = torch.empty(T, d, dtype=f32, device=dev)
+            if p_r > 0:
+                y = torch.empty(T, d, dtype=bf, device=dev)
+                ops.conv1d_fwd(x, w, b, y)
+                ops.dropout_resid(y, resid, out, p_r, key)
+            else:
+                ops.conv1d_fwd(x, w, b, out, ops.OUT_F32_RESID_BF16ROUND, resid)
+            return out
+
         for l, v in enumerate(self._layers):
             x1 = torch.empty(T, d, dtype=bf, device=dev)
             mean1 = torch.empty(T, dtype=f32, device=dev)
@@ -126,9 +159,9 @@ class MidiGPT2LM(MidiLM):
                               cache.max_len)
             att = torch.empty(T, d, dtype=bf, device=dev)
             lse = torch.empty(B, H, S, dtype=f32, device=dev)
-            ops.attn_fwd(qp, kp, vp, att.data_ptr(), lse, 3 * d, 3 * d, 3 * d, d, B, S, H, H, Dh, scale)
-            h_mid = torch.empty(T, d, dtype=f32, device=dev)
-            ops.conv1d_fwd(att, v.s_proj, v.s_proj_b, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
+            ops.attn_fwd(qp, kp, vp, att.data_ptr(), lse, 3 * d, 3 * d, 3 * d, d, B, S, H, H, Dh, scale,
+                         drop_p=p_a, drop_key=keys[3 * l + 1] if keys else 0)
+            h_mid = proj_resid(att, v.s_proj, v.s_proj_b, h, keys[3 * l + 2] if keys else 0)
             x2 = torch.empty(T, d, dtype=bf, device=dev)
             mean2 = torch.empty(T, dtype=f32, device=dev)
             rstd2 = torch.empty(T, dtype=f32, device=dev)
@@ -137,8 +170,7 @@ class MidiGPT2LM(MidiLM):
             ops.conv1d_fwd(x2, v.s_fc, v.s_fc_b, fc)
             act = torch.empty(T, I, dtype=bf, device=dev)
             ops.gelu_new_fwd(fc, act)
-            h_out = torch.empty(T, d, dtype=f32, device=dev)
-            ops.conv1d_fwd(act, v.s_mproj, v.s_mproj_b, h_out, ops.OUT_F32_RESID_BF16ROUND, h_mid)
+            h_out = proj_resid(act, v.s_mproj, v.s_mproj_b, h_mid, keys[3 * l + 3] if keys else 0)
             if save is not None:
                 save.append((h, x1, mean1, rstd1, qkv, att, lse, h_mid, x2, mean2, rstd2, fc, act))
             h = h_out
@@ -146,7 +178,7 @@ class MidiGPT2LM(MidiLM):
         meanN = torch.empty(T, dtype=f32, device=dev)
         rstdN = torch.empty(T, dtype=f32, device=dev)
         ops.layernorm_fwd(h, self.transformer.ln_f.weight, self.transformer.ln_f.bias, xN, meanN, rstdN, eps)
-        return xN, (h, meanN, rstdN)
+        return xN, (h, meanN, rstdN, keys)
 
     # ---- backward ------------------------------------------------------------------------------------------
     def _backward_layers(self, input_ids, saved, final, dxN, grad_hook=None):
@@ -156,7 +188,9 @@ class MidiGPT2LM(MidiLM):
         d, H, Dh, I = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.intermediate_size
         dev, bf, f32 = input_ids.device, torch.bfloat16, torch.float32
         scale = Dh ** -0.5
-        h_last, meanN, rstdN = final
+        h_last, meanN, rstdN, keys = final
+        p_e, p_r, p_a = (cfg.embd_pdrop, cfg.resid_pdrop, cfg.attn_pdrop) if keys else (0.0, 0.0, 0.0)
+        dy = torch.empty(T, d, dtype=bf, device=dev) if p_r > 0 else None   # gradient of a dropped projection output
         dh = torch.empty(T, d, dtype=f32, device=dev)
         dh_lp = torch.empty(T, d, dtype=bf, device=dev)
         ops.layernorm_bwd(dxN, h_last, self.transformer.ln_f.weight, meanN, rstdN, dh, dh_lp,
@@ -174,19 +208,28 @@ class MidiGPT2LM(MidiLM):
             v = self._layers[l]
             h_in, x1, mean1, rstd1, qkv, att, lse, h_mid, x2, mean2, rstd2, fc, act = saved[l]
             # ---- MLP branch
-            ops.conv1d_dgrad(dh_lp, v.s_mproj, dact)
-            ops.conv1d_wgrad(dh_lp, act, v.g_mproj, v.g_mproj_b)
+            g = dh_lp
+            if p_r > 0:
+                ops.dropout(dh_lp, dy, p_r, keys[3 * l + 3])
+                g = dy
+            ops.conv1d_dgrad(g, v.s_mproj, dact)
+            ops.conv1d_wgrad(g, act, v.g_mproj, v.g_mproj_b)
             ops.gelu_new_bwd(fc, dact, dfc)
             ops.conv1d_dgrad(dfc, v.s_fc, dx)
             ops.conv1d_wgrad(dfc, x2, v.g_fc, v.g_fc_b)
             ops.layernorm_bwd(dx, h_mid, v.w_ln2w, mean2, rstd2, dh, dh_lp, v.g_ln2w, v.g_ln2b, accumulate=True)
             # ---- attention branch
-            ops.conv1d_dgrad(dh_lp, v.s_proj, datt)
-            ops.conv1d_wgrad(dh_lp, att, v.g_proj, v.g_proj_b)
+            g = dh_lp
+            if p_r > 0:
+                ops.dropout(dh_lp, dy, p_r, keys[3 * l + 2])
+                g = dy
+            ops.conv1d_dgrad(g, v.s_proj, datt)
+            ops.conv1d_wgrad(g, att, v.g_proj, v.g_proj_b)
             qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
             dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + 2 * d, dqkv.data_ptr() + 4 * d
             ops.attn_bwd(qp, kp, vp, att.data_ptr(), datt.data_ptr(), lse, delta, dqp, dkp, dvp,
-                         3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, B, S, H, H, Dh, scale)
+                         3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, B, S, H, H, Dh, scale,
+                         drop_p=p_a, drop_key=keys[3 * l + 1] if keys else 0)
             ops.conv1d_dgrad(dqkv, v.s_attn, dx)
             ops.conv1d_wgrad(dqkv, x1, v.g_attn, v.g_attn_b)
             ops.layernorm_bwd(dx, h_in, v.w_ln1w, mean1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1w, v.g_ln1b,
@@ -194,6 +237,8 @@ class MidiGPT2LM(MidiLM):
             saved[l] = None
             if grad_hook is not None:
                 grad_hook(l)
+        if p_e > 0:
+            ops.dropout(dh, dh, p_e, keys[0])
         ops.embedding_bwd(input_ids, dh, self._view(self.flat_grad, "transformer.wte.weight"))
         pos_ids = torch.arange(S, device=dev, dtype=torch.int64).repeat(B)
         ops.embedding_bwd(pos_ids, dh, self._view(self.flat_grad, "transformer.wpe.weight"))

@@ -4,8 +4,10 @@ Reference: `MidiAria.to_lora` (/root/reference/src/model/model.py:251-271) freez
 model with peft's `LoraConfig(r=32, lora_alpha=64, lora_dropout=0.05, bias="none")` on the fused QKV projection, the
 attention output projection and the gate / up / down projections. peft's linear layer computes
 `base(x) + lora_B(lora_A(dropout(x))) * (alpha / r)` with A ~ kaiming_uniform(a=sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in))
-and B = 0. peft is not installed here: the arithmetic is restated from that formula (parity unpinned); the adapter
-dropout is not applied (p = 0), as for the other dropouts of this build.
+and B = 0. peft is not installed here: the arithmetic is restated from that formula (parity unpinned). The adapter
+dropout (`dropout=`, training mode only) masks the adapter's input with a hash of (key, element index); every site of
+every forward has its own key and the backward pass recomputes the masks, as peft's per-layer Dropout modules draw
+independent masks. With dropout on, the gate and up adapters no longer share one product (their inputs differ).
 
 Here the adapters live in one small flat fp32 buffer (+ gradient, + bf16 shadow) next to the frozen model. Each site
 costs two extra products in the forward pass, t = s * x A^T (N = r) and y += t B^T (K = r, added straight into the
@@ -28,13 +30,17 @@ class _Site:
 
 
 class LoraAdapters:
-    def __init__(self, model, r=32, alpha=64, seed=0):
+    def __init__(self, model, r=32, alpha=64, seed=0, dropout=0.0):
         cfg = model.cfg
         if r % 8 or r <= 0:
             raise ValueError("the adapter rank must be a positive multiple of 8")
         if cfg.arch != "llama" or cfg.pos4d or model.act_dtype != torch.bfloat16:
             raise NotImplementedError("adapters cover the bf16-mixed token models with RMSNorm/RoPE/SwiGLU blocks")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError("the adapter dropout probability must be in [0, 1)")
         self.r, self.alpha, self.scale = r, alpha, alpha / r
+        self.dropout_p, self.dropout_seed, self._dropout_calls = float(dropout), int(seed), 0
+        self._scratch = {}
         d, I = cfg.hidden_size, cfg.intermediate_size
         NQ, HD = cfg.qkv_width, cfg.num_attention_heads * cfg.head_dim
         # (in, out) of every site; gate and up sit back to back so that one product with [A_gate; A_up] serves both
@@ -102,14 +108,40 @@ class LoraAdapters:
     def named_parameters(self):
         return list(self._names.items())
 
+    # ---- dropout ---------------------------------------------------------------------------------------------
+    def drop_keys(self, training: bool):
+        """Per layer, the five mask keys (SITES order) of this forward; None when the adapter dropout is off."""
+        if not training or self.dropout_p == 0.0:
+            return None
+        n = len(SITES) * len(self.layers)
+        base = self._dropout_calls * n
+        self._dropout_calls += 1
+        return [[ops.dropout_key(self.dropout_seed, base + len(SITES) * l + i) for i in range(len(SITES))]
+                for l in range(len(self.layers))]
+
+    def _buf(self, like):
+        b = self._scratch.get(tuple(like.shape))
+        if b is None or b.device != like.device:
+            b = self._scratch[tuple(like.shape)] = torch.empty_like(like)
+        return b
+
+    def _dropped(self, x, key):
+        xd = self._buf(x)
+        ops.dropout(x, xd, self.dropout_p, key)
+        return xd
+
     # ---- one site ------------------------------------------------------------------------------------------
-    def fwd(self, x, sA, sB, y, n_in, n_out, r_cols=None):
-        """t = s * x A^T (returned, bf16 [T, rows of A]); y[:, :n_out] += t B^T. `y` is the base projection's output:
-        bf16, or the fp32 residual stream."""
+    def fwd(self, x, sA, sB, y, n_in, n_out, key=None, t=None):
+        """t = s * dropout(x) A^T (returned, bf16 [T, rows of A]); y[:, :n_out] += t B^T. `y` is the base projection's
+        output: bf16, or the fp32 residual stream. key: the site's dropout key (None = no dropout); t: where to put
+        the product (a column block of a wider buffer) instead of a new tensor."""
         T = x.shape[0]
         rr = sA.shape[0]
-        t = torch.empty(T, rr, dtype=torch.bfloat16, device=x.device)
-        ops.gemm(x, sA, t, T, rr, n_in, x.stride(0), sA.stride(0), rr, alpha=self.scale)
+        if key is not None:
+            x = self._dropped(x, key)
+        if t is None:
+            t = torch.empty(T, rr, dtype=torch.bfloat16, device=x.device)
+        ops.gemm(x, sA, t, T, rr, n_in, x.stride(0), sA.stride(0), t.stride(0), alpha=self.scale)
         if sB is not None:
             self.add_out(t, sB, y, n_out)
         return t
@@ -119,15 +151,20 @@ class LoraAdapters:
         mode = ops.OUT_F32_ACC if y.dtype == torch.float32 else ops.OUT_BF16_ACC
         ops.gemm(t, sB, y, T, n_out, self.r, t.stride(0), sB.stride(0), y.stride(0), out_mode=mode)
 
-    def bwd(self, dy, x, t, sA, sB, gA, gB, dx, n_in, n_out):
+    def bwd(self, dy, x, t, sA, sB, gA, gB, dx, n_in, n_out, key=None):
         """dy [T, n_out] (bf16), x [T, n_in], t from fwd. Accumulates gA, gB; adds the adapter's share to dx (which
-        already holds dy W)."""
+        already holds dy W). key: the dropout key the forward call of this site used."""
         T = dy.shape[0]
         r = self.r
         dt = torch.empty(T, r, dtype=torch.bfloat16, device=dy.device)
         ops.gemm(dy, sB, dt, T, r, n_out, dy.stride(0), sB.stride(0), r, trans_b=True, alpha=self.scale)
         ops.gemm(dy, t, gB, n_out, r, T, dy.stride(0), t.stride(0), gB.stride(0), True, True, ops.OUT_F32_ACC)
-        ops.gemm(dt, x, gA, r, n_in, T, r, x.stride(0), gA.stride(0), True, True, ops.OUT_F32_ACC)
-        if dx is not None:
+        xin = self._dropped(x, key) if key is not None else x
+        ops.gemm(dt, xin, gA, r, n_in, T, r, xin.stride(0), gA.stride(0), True, True, ops.OUT_F32_ACC)
+        if dx is not None and key is None:
             ops.gemm(dt, sA, dx, T, n_in, r, r, sA.stride(0), dx.stride(0), False, True, ops.OUT_BF16_ACC)
+        elif dx is not None:   # the adapter's input gradient passes the mask before it joins the base path's
+            tmp = self._buf(x)     # (stream order: the product above has consumed the dropped input by now)
+            ops.gemm(dt, sA, tmp, T, n_in, r, r, sA.stride(0), tmp.stride(0), False, True, ops.OUT_BF16)
+            ops.dropout_add(tmp, dx, self.dropout_p, key)
         return dt

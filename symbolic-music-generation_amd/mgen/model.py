@@ -172,16 +172,17 @@ class MidiLM(GenerationMixin, nn.Module):
     # ------------------------------------------------------------------------------------------------
     # low-rank adapters
     # ------------------------------------------------------------------------------------------------
-    def to_lora(self, r: int = 32, lora_alpha: int = 64, seed: int = 0):
+    def to_lora(self, r: int = 32, lora_alpha: int = 64, seed: int = 0, lora_dropout: float = 0.0):
         """`MidiAria.to_lora` (/root/reference/src/model/model.py:251-271): freeze every base weight and train
         rank-r adapters on the fused QKV, attention output, gate, up and down projections. Returns the adapter
-        store (its flat buffers are what the fused optimizer and the gradient reducer then work on)."""
+        store (its flat buffers are what the fused optimizer and the gradient reducer then work on). `lora_dropout`
+        (0.05 in the reference) masks each adapter's input in training mode."""
         from .lora import LoraAdapters
         if self.lora is not None:
             raise RuntimeError("the model already carries adapters")
         for prm in self.parameters():
             prm.requires_grad = False
-        self.lora = LoraAdapters(self, r, lora_alpha, seed)
+        self.lora = LoraAdapters(self, r, lora_alpha, seed, dropout=lora_dropout)
         return self.lora
 
     def merge_lora(self):
@@ -456,15 +457,17 @@ class MidiLM(GenerationMixin, nn.Module):
             cs = self._rope_table(S)
             ops.embedding_fwd(inp, self.model.embed_tokens.weight, h, self._err_flag)
         lo = self.lora
+        lkeys = lo.drop_keys(self.training and cache is None and pos is None) if lo is not None else None
         for l, v in enumerate(self._layers):
             la = lo.layers[l] if lo is not None else None
+            lk = lkeys[l] if lkeys is not None else (None,) * 5   # adapter dropout keys: qkv, o, gate, up, down
             x1 = torch.empty(T, d, dtype=bf, device=dev)
             rstd1 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h, v.w_ln1, x1, rstd1, cfg.rms_norm_eps)
             qkv = torch.empty(T, NQ, dtype=bf, device=dev)
             ops.linear_fwd(x1, v.s_qkv, qkv)
             if la is not None:   # adapters: y += s (x A^T) B^T, added into the base projection's output
-                t_qkv = lo.fwd(x1, la["qkv"].sA, la["qkv"].sB, qkv, d, NQ)
+                t_qkv = lo.fwd(x1, la["qkv"].sA, la["qkv"].sB, qkv, d, NQ, key=lk[0])
             if cfg.pos4d:
                 # q, k (normalised) and v all rotated: one [T, NQ] buffer in the layout of qkv
                 qk = torch.empty(T, NQ, dtype=bf, device=dev)
@@ -490,25 +493,29 @@ class MidiLM(GenerationMixin, nn.Module):
             h_mid = torch.empty(T, d, dtype=torch.float32, device=dev)
             ops.linear_fwd(att_o, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
             if la is not None:
-                t_o = lo.fwd(att_o, la["o"].sA, la["o"].sB, h_mid, H * Dh, d)
+                t_o = lo.fwd(att_o, la["o"].sA, la["o"].sB, h_mid, H * Dh, d, key=lk[1])
             x2 = torch.empty(T, d, dtype=bf, device=dev)
             rstd2 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h_mid, v.w_ln2, x2, rstd2, cfg.rms_norm_eps)
             gu = torch.empty(T, 2 * I, dtype=bf, device=dev)
             ops.linear_fwd(x2, v.s_gu, gu)
-            if la is not None:   # one product with [A_gate; A_up], then each half through its own B
+            if la is not None and lk[2] is None:   # one product with [A_gate; A_up], then each half through its own B
                 t_gu = lo.fwd(x2, la["gu_sA"], None, None, d, 0)
                 lo.add_out(t_gu[:, :lo.r], la["gate"].sB, gu[:, :I], I)
                 lo.add_out(t_gu[:, lo.r:], la["up"].sB, gu[:, I:], I)
+            elif la is not None:   # dropout: the two adapters see differently masked inputs
+                t_gu = torch.empty(T, 2 * lo.r, dtype=bf, device=dev)
+                lo.fwd(x2, la["gate"].sA, la["gate"].sB, gu[:, :I], d, I, key=lk[2], t=t_gu[:, :lo.r])
+                lo.fwd(x2, la["up"].sA, la["up"].sB, gu[:, I:], d, I, key=lk[3], t=t_gu[:, lo.r:])
             act = torch.empty(T, I, dtype=bf, device=dev)
             ops.swiglu_fwd(gu, act)
             h_out = torch.empty(T, d, dtype=torch.float32, device=dev)
             ops.linear_fwd(act, v.s_down, h_out, ops.OUT_F32_RESID_BF16ROUND, h_mid)
             if la is not None:
-                t_down = lo.fwd(act, la["down"].sA, la["down"].sB, h_out, I, d)
+                t_down = lo.fwd(act, la["down"].sA, la["down"].sB, h_out, I, d, key=lk[4])
             if save is not None:
                 save.append((h, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o,
-                             (t_qkv, t_o, t_gu, t_down) if la is not None else None))
+                             (t_qkv, t_o, t_gu, t_down, lk) if la is not None else None))
             h = h_out
         xN = torch.empty(T, d, dtype=bf, device=dev)
         rstdN = torch.empty(T, dtype=torch.float32, device=dev)
@@ -601,7 +608,8 @@ class MidiLM(GenerationMixin, nn.Module):
             if la is None:
                 ops.linear_wgrad(dh_lp, act, v.g_down)
             else:
-                lo.bwd(dh_lp, act, lts[3], la["down"].sA, la["down"].sB, la["down"].gA, la["down"].gB, dact, I, d)
+                lo.bwd(dh_lp, act, lts[3], la["down"].sA, la["down"].sB, la["down"].gA, la["down"].gB, dact, I, d,
+                       key=lts[4][4])
             ops.swiglu_bwd(gu, dact, dgu)
             ops.linear_dgrad(dgu, v.s_gu, dx)
             if la is None:
@@ -609,15 +617,17 @@ class MidiLM(GenerationMixin, nn.Module):
             else:
                 r_ = lo.r
                 lo.bwd(dgu[:, :I], x2, lts[2][:, :r_], la["gate"].sA, la["gate"].sB, la["gate"].gA, la["gate"].gB,
-                       dx, d, I)
-                lo.bwd(dgu[:, I:], x2, lts[2][:, r_:], la["up"].sA, la["up"].sB, la["up"].gA, la["up"].gB, dx, d, I)
+                       dx, d, I, key=lts[4][2])
+                lo.bwd(dgu[:, I:], x2, lts[2][:, r_:], la["up"].sA, la["up"].sB, la["up"].gA, la["up"].gB, dx, d, I,
+                       key=lts[4][3])
             ops.rmsnorm_bwd(dx, h_mid, v.w_ln2, rstd2, dh, dh_lp, v.g_ln2, accumulate=True)
             # ---- attention branch
             ops.linear_dgrad(dh_lp, v.s_o, datt)
             if la is None:
                 ops.linear_wgrad(dh_lp, att_o, v.g_o)
             else:
-                lo.bwd(dh_lp, att_o, lts[1], la["o"].sA, la["o"].sB, la["o"].gA, la["o"].gB, datt, H * Dh, d)
+                lo.bwd(dh_lp, att_o, lts[1], la["o"].sA, la["o"].sB, la["o"].gA, la["o"].gB, datt, H * Dh, d,
+                       key=lts[4][1])
             dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + esz * H * Dh, dqkv.data_ptr() + esz * QK
             if cfg.pos4d:
                 # datt is the gradient of the rotated-back output: rotate it forward to reach the attention output
@@ -639,7 +649,8 @@ class MidiLM(GenerationMixin, nn.Module):
             if la is None:
                 ops.linear_wgrad(dqkv, x1, v.g_qkv)
             else:
-                lo.bwd(dqkv, x1, lts[0], la["qkv"].sA, la["qkv"].sB, la["qkv"].gA, la["qkv"].gB, dx, d, NQ)
+                lo.bwd(dqkv, x1, lts[0], la["qkv"].sA, la["qkv"].sB, la["qkv"].gA, la["qkv"].gB, dx, d, NQ,
+                       key=lts[4][0])
             ops.rmsnorm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, accumulate=True)
             saved[l] = None
             if grad_hook is not None:

@@ -296,17 +296,63 @@ def notes_to_events(rows, ticks_per_second, ticks, msgs):
     call("mgen_notes_to_events", _p(rows), rows.shape[0], float(ticks_per_second), _p(ticks), _p(msgs), _stream())
 
 
-def attn_fwd(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, D, scale, f32=False):
+def attn_fwd(q, k, v, out, lse, sq, sk, sv, so, B, S, H, KVH, D, scale, f32=False, drop_p=0.0, drop_key=0):
     """q/k/v/out are raw device pointers (ints) of token-major views (bf16, or fp32 with f32=True); strides in
-    elements."""
+    elements. drop_p > 0: dropout on the attention probabilities with the mask of `drop_key` (bf16 kernels only)."""
+    if drop_p > 0.0:
+        if f32:
+            raise NotImplementedError("attention dropout exists for the bf16 kernels only")
+        call("mgen_attn_fwd_dropout", q, k, v, out, _p(lse), sq, sk, sv, so, B, S, H, KVH, D, scale, float(drop_p),
+             int(drop_key), _stream())
+        return
     call("mgen_attn_f32_fwd" if f32 else "mgen_attn_fwd", q, k, v, out, _p(lse), sq, sk, sv, so, B, S, H, KVH, D,
          scale, _stream())
 
 
 def attn_bwd(q, k, v, out, dout, lse, delta, dq, dk, dv, sq, sk, sv, so, sdo, sdq, sdk, sdv, B, S, H, KVH, D, scale,
-             f32=False):
+             f32=False, drop_p=0.0, drop_key=0):
+    if drop_p > 0.0:
+        if f32:
+            raise NotImplementedError("attention dropout exists for the bf16 kernels only")
+        call("mgen_attn_bwd_dropout", q, k, v, out, dout, _p(lse), _p(delta), dq, dk, dv, sq, sk, sv, so, sdo, sdq,
+             sdk, sdv, B, S, H, KVH, D, scale, float(drop_p), int(drop_key), _stream())
+        return
     call("mgen_attn_f32_bwd" if f32 else "mgen_attn_bwd", q, k, v, out, dout, _p(lse), _p(delta), dq, dk, dv, sq, sk,
          sv, so, sdo, sdq, sdk, sdv, B, S, H, KVH, D, scale, _stream())
+
+
+def dropout(x, y, p, key):
+    """y = dropout(x) with the mask of `key` (x, y contiguous bf16 or fp32 of one type; y may be x). The gradient is
+    the same call on the upstream gradient."""
+    _need_gpu(x, y)
+    assert x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    call("mgen_dropout", _p(x), _p(y), x.numel(), int(x.dtype == torch.bfloat16), float(p), int(key), _stream())
+
+
+def dropout_add(x, y, p, key):
+    """y += dropout(x) with the mask of `key` (same type, contiguous, not aliased)."""
+    _need_gpu(x, y)
+    assert x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    call("mgen_dropout_add", _p(x), _p(y), x.numel(), int(x.dtype == torch.bfloat16), float(p), int(key), _stream())
+
+
+def dropout_resid(y, resid, out, p, key):
+    """out (fp32) = resid (fp32) + bf16-rounded dropout(y) (y bf16)."""
+    _need_gpu(y, resid, out)
+    assert y.dtype == torch.bfloat16 and resid.dtype == torch.float32 and out.dtype == torch.float32
+    assert y.is_contiguous() and resid.is_contiguous() and out.is_contiguous()
+    call("mgen_dropout_resid", _p(y), _p(resid), _p(out), y.numel(), float(p), int(key), _stream())
+
+
+_M64 = (1 << 64) - 1
+
+
+def dropout_key(seed: int, counter: int) -> int:
+    """One 64-bit mask key per (seed, dropout site): splitmix64 of seed + counter * golden ratio."""
+    z = (int(seed) + (int(counter) + 1) * 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
 
 
 def swiglu_fwd(gu, act, round_silu=True):

@@ -25,6 +25,7 @@ class GradReducer:
         self.model = model
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.min_bucket = min_bucket_elems
         self._pending = []
         self._open: Optional[list] = None  # [start, end) of the bucket being grown (ranges arrive high -> low)
@@ -76,8 +77,12 @@ class Trainer:
         self.model = model
         self.opt, self.sched = get_optim(model, lr, num_epochs, steps_per_epoch, warmup, max_grad_norm=max_grad_norm)
         self.reducer = GradReducer(model, group)
+        for holder in (model, getattr(model, "lora", None)):   # every replica draws its own dropout masks
+            if hasattr(holder, "dropout_seed"):
+                holder.dropout_seed += 1000003 * self.reducer.rank
 
     def training_step(self, batch):
+        self.model.train()
         self.opt.zero_grad()
         loss = self.model(**batch).loss
         loss.backward()
@@ -88,6 +93,7 @@ class Trainer:
 
     @torch.no_grad()
     def validation_step(self, batch):
+        self.model.eval()
         loss = self.model(**batch).loss
         if self.reducer.world > 1:  # self.log(..., sync_dist=True): mean over ranks
             dist.all_reduce(loss, op=dist.ReduceOp.AVG, group=self.reducer.group)

@@ -125,10 +125,10 @@ class MidiAria(_Wrapper):
         self.model = MidiLM(config or aria_style_llama(), device=device, seed=seed)
 
     def to_lora(self):
-        """/root/reference/src/model/model.py:251-271: freeze the base, rank-32 adapters (alpha 64) on the fused QKV,
-        attention output, gate, up and down projections. Call it before configure_optimizers(): the optimizer then
-        covers the adapters only. (The reference's adapter dropout of 0.05 is not applied.)"""
-        return self.model.to_lora(r=32, lora_alpha=64)
+        """/root/reference/src/model/model.py:251-271: freeze the base, rank-32 adapters (alpha 64, dropout 0.05) on
+        the fused QKV, attention output, gate, up and down projections. Call it before configure_optimizers(): the
+        optimizer then covers the adapters only."""
+        return self.model.to_lora(r=32, lora_alpha=64, lora_dropout=0.05)
 
 
 class MidiGPT2(_Wrapper):

@@ -488,6 +488,70 @@ def gpt2_case(name="tiny_gpt2", B=2, S=128):
           "last", losses[-1])
 
 
+def gpt2_dropout_case(name="tiny_gpt2_dropout", B=2, S=128, seed=11, pdrop=0.1):
+    """The same GPT2LMHeadModel in training mode with the GPT2Config default dropout of 0.1 (what the reference
+    trains with). torch's own mask stream cannot be reproduced elsewhere, so torch.nn.functional.dropout is replaced
+    for the duration of the forward by a function that applies the masks of oracle.ref_dropout in call order
+    (embeddings; per block: attention probabilities, attention projection, MLP projection) with torch's arithmetic
+    x * mask / (1 - p). What the fixture pins is WHERE transformers applies its dropouts and how they enter the loss
+    and the gradients; the mask stream itself stays this build's own."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from oracle import ref_gpt2 as G
+    from oracle import ref_dropout as RD
+    import torch.nn.functional as F
+    cfg = R.LMConfig(vocab_size=1000, hidden_size=256, intermediate_size=1024, num_hidden_layers=2,
+                     num_attention_heads=4, num_key_value_heads=4, head_dim=64, max_position_embeddings=1024,
+                     tie_word_embeddings=True, qk_norm=False)
+    params = G.init_params_gpt2(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    for k in params:
+        if ".ln_" in k or k.endswith(".bias"):
+            params[k] = params[k] + 0.1 * torch.randn(params[k].shape, generator=g)
+    hc = GPT2Config(vocab_size=cfg.vocab_size, n_positions=cfg.max_position_embeddings, n_embd=cfg.hidden_size,
+                    n_layer=cfg.num_hidden_layers, n_head=cfg.num_attention_heads, resid_pdrop=pdrop,
+                    embd_pdrop=pdrop, attn_pdrop=pdrop, bos_token_id=1, eos_token_id=2, pad_token_id=0,
+                    attn_implementation="eager")
+    m = GPT2LMHeadModel(hc)
+    missing, unexpected = m.load_state_dict(params, strict=False)
+    assert not unexpected and all(k == "lm_head.weight" for k in missing), (missing, unexpected)
+    m.tie_weights()
+    m.train()
+    plan = RD.DropPlan(seed, 0, cfg.num_hidden_layers, pdrop, pdrop, pdrop)
+    calls = []
+
+    def planned_dropout(x, p=0.5, training=True, inplace=False):
+        site = len(calls)
+        calls.append(tuple(x.shape))
+        assert training and abs(p - pdrop) < 1e-12
+        if x.dim() == 4:   # attention probabilities [B, H, S, S]
+            keep = RD.keep_attn(plan.key(site), x.shape[0], x.shape[1], x.shape[2], p)
+        else:
+            keep = RD.keep_flat(plan.key(site), x.numel(), p).view(x.shape)
+        return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+
+    gen = torch.Generator().manual_seed(1234)
+    ids = torch.randint(3, cfg.vocab_size, (B, S), generator=gen)
+    real = F.dropout
+    F.dropout = planned_dropout
+    try:
+        m.zero_grad()
+        o = m(input_ids=ids, labels=ids)
+        o.loss.backward()
+    finally:
+        F.dropout = real
+    L = cfg.num_hidden_layers
+    want = [(B, S, cfg.hidden_size)] + [(B, cfg.num_attention_heads, S, S), (B, S, cfg.hidden_size),
+                                        (B, S, cfg.hidden_size)] * L
+    assert calls == want, calls
+    out = {"param_checksum": checksum(params), "input_ids": ids.numpy(), "seed": seed, "pdrop": pdrop,
+           "fp32_loss": o.loss.item(), "fp32_logits": slim(o.logits.detach().numpy())}
+    gr = grads_of(m)
+    for k in GPT2_GRAD_KEYS:
+        out["fp32_grad/" + k] = slim(gr[k].numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "fp32 loss with dropout", out["fp32_loss"], "sites", len(calls))
+
+
 def load_reference_collate():
     """Pull the batch-assembly functions out of the reference's training scripts without importing those scripts
     (their top-level imports need miditok / symusic / lightning, absent here): the function definitions are compiled
@@ -552,6 +616,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--gpt2-only" in sys.argv:
         gpt2_case()
+        sys.exit(0)
+    if "--gpt2-dropout-only" in sys.argv:
+        gpt2_dropout_case()
         sys.exit(0)
     tiny_q = R.LMConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                         num_attention_heads=2, num_key_value_heads=2, head_dim=128)
