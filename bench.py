@@ -119,6 +119,9 @@ def main():
     from mgen import MidiLM, default_decoder, aria_style_llama, ops
     from mgen.trainer import Trainer, init_distributed_from_env
 
+    if os.environ.get("MGEN_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MGEN_BENCH_WATCHDOG"]), exit=True)
     rank, local, world = init_distributed_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False)")

@@ -641,7 +641,11 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* out, 
     if (int e = set_drop(a, p, key, who)) return e;
     MGEN_REQUIRE(so % 8 == 0 && sdo % 8 == 0 && sdq % 4 == 0 && sdk % 4 == 0 && sdv % 4 == 0,
                  "%s: bad token stride alignment", who);
-    static bool attr_set = false;
+    // more than the default 64 KiB of dynamic LDS has to be asked for, once per kernel and device
+    static bool asked[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    bool& attr_set = asked[dev];
     if (!attr_set) {
         if (int e = set_lds(attn_bwd_dkv_kernel<128, false>, 2 * DKV_BUF, who)) return e;
         if (int e = set_lds(attn_bwd_dkv_kernel<64, false>, 2 * DKV_BUF, who)) return e;

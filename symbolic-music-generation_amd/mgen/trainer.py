@@ -42,8 +42,24 @@ class GradReducer:
         s, e = self._open
         self._open = None
         buf = self.model.flat_grad[s:e]
-        op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
-        self._pending.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf))
+        self._pending.append((self._start(buf), buf))
+
+    def _start(self, buf):
+        """Begin the reduction of one slice; returns something with .wait()."""
+        if self._native_avg:
+            return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        if buf.is_cuda:
+            # gloo rehearsal on device tensors (several ranks sharing one GPU): staged through host memory, blocking.
+            # Only the control flow is like the RCCL path.
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(host)
+
+            class _Done:
+                def wait(self):
+                    return None
+            return _Done()
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_range_done(self, tag):
         s, e = self._ranges[tag]
@@ -57,9 +73,8 @@ class GradReducer:
 
     def wait(self):
         if self._lora is not None and self.world > 1:
-            op = dist.ReduceOp.AVG if self._native_avg else dist.ReduceOp.SUM
             buf = self._lora.flat_grad
-            self._pending.append((dist.all_reduce(buf, op=op, group=self.group, async_op=True), buf))
+            self._pending.append((self._start(buf), buf))
         self._flush()
         for w, buf in self._pending:
             w.wait()
@@ -105,9 +120,14 @@ def init_distributed_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MGEN_REHEARSE_ON_ONE_GPU=1: every rank uses device 0 and the exchange goes through gloo (RCCL refuses two ranks
+    # on one device) - for running the multi-rank code path on a one-GPU machine, not for measurements
+    rehearse = os.environ.get("MGEN_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = "nccl" if torch.cuda.is_available() and not rehearse else "gloo"
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
