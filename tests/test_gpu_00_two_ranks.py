@@ -1,7 +1,10 @@
 """bench.py launched the way the multi-GPU measurement launches it (torch.distributed.run, one process per rank), with
 two ranks sharing the one GPU of the test machine: MGEN_REHEARSE_ON_ONE_GPU=1 puts both on device 0 and routes the
 gradient exchange through gloo (RCCL refuses two ranks on one device). Checks the control flow of the N > 1 path -
-gradient hooks and buckets, barriers, the max-over-ranks time, one JSON line from rank 0 - not its speed."""
+gradient hooks and buckets, barriers, the max-over-ranks time, one JSON line from rank 0 - not its speed.
+
+The file name sorts before the other GPU tests on purpose: the child processes are started while this process has
+not touched the GPU yet."""
 import json
 import os
 import socket
