@@ -207,6 +207,13 @@ int mgen_attn_f32_bwd(const float* q, const float* k, const float* v, const floa
                       const float* lse, float* delta, float* dq, float* dk, float* dv, long sq, long sk, long sv, long so,
                       long sdo, long sdq, long sdk, long sdv, int B, int S, int H, int KVH, int D, float scale,
                       mgen_stream_t stream);
+/* GPT-2 blocks in the fp32 parity mode (fp32 activations): gelu_new (TF activations.py NewGELUActivation) and the
+ * Conv1D bias (TF pytorch_utils.py Conv1D.forward, addmm(bias, x, W)) with its gradient. n, N, ld multiples of 4. */
+int mgen_gelu_new_f32_fwd(const float* h, float* act, long n, mgen_stream_t stream);
+int mgen_gelu_new_f32_bwd(const float* h, const float* dact, float* dh, long n, mgen_stream_t stream);
+int mgen_bias_add_f32(float* y, long ld, const float* bias, long T, int N, mgen_stream_t stream);
+int mgen_colsum_f32(const float* x, long ld, float* out, long T, int N, mgen_stream_t stream);
+
 
 /* ---- batch assembly on the device ---------------------------------------------------------------------------------
  * Token batches: flat = the B examples back to back, offsets[B+1]; outputs [B][S] int64 right-padded with pad_id.

@@ -304,3 +304,113 @@ extern "C" int mgen_attn_f32_bwd(const float* q, const float* k, const float* v,
     }
     return mgen_check_launch("mgen_attn_f32_bwd");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// GPT-2 blocks in the fp32 parity mode: gelu_new, the Conv1D bias and its gradient on fp32 activations
+// (transformers activations.py NewGELUActivation; pytorch_utils.py Conv1D.forward = addmm(bias, x, W)).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr float kGeluA32 = 0.7978845608028654f;  // sqrt(2/pi)
+constexpr float kGeluB32 = 0.044715f;
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void gelu_f32_kernel(const float* __restrict__ h, const float* __restrict__ dact,
+                                                       float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(h)[i];
+        f32x4 o;
+        f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+        if (BWD) dv = reinterpret_cast<const f32x4*>(dact)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float u = kGeluA32 * (x[e] + kGeluB32 * x[e] * x[e] * x[e]);
+            const float t = tanhf(u);
+            if (BWD) {
+                const float du = kGeluA32 * (1.0f + 3.0f * kGeluB32 * x[e] * x[e]);
+                o[e] = dv[e] * (0.5f * (1.0f + t) + 0.5f * x[e] * (1.0f - t * t) * du);
+            } else {
+                o[e] = 0.5f * x[e] * (1.0f + t);
+            }
+        }
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+// y[t][n] += bias[n]
+__global__ __launch_bounds__(256) void bias_add_f32_kernel(float* __restrict__ y, long ld, const float* __restrict__ bias,
+                                                           long T, int N) {
+    const int nv = N / 4;
+    const long total = T * nv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long t = i / nv;
+        const int c = (int)(i % nv) * 4;
+        f32x4* p = reinterpret_cast<f32x4*>(y + t * ld + c);
+        *p = *p + *reinterpret_cast<const f32x4*>(bias + c);
+    }
+}
+
+// out[n] += sum_t x[t][n]: 256 threads = 64 column groups of 4 x 4 row lanes, a strip of rows per block
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, long ld, float* __restrict__ out,
+                                                         long T, int N, long rows_per_block) {
+    __shared__ float red[4][64][4];
+    const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = (blockIdx.x * 64 + cg) * 4;
+    const long t0 = (long)blockIdx.y * rows_per_block;
+    const long t1 = t0 + rows_per_block < T ? t0 + rows_per_block : T;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (n < N)
+        for (long t = t0 + rl; t < t1; t += 4) s += *reinterpret_cast<const f32x4*>(x + t * ld + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rl][cg][e] = s[e];
+    __syncthreads();
+    if (rl == 0 && n < N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            atomicAdd(out + n + e, red[0][cg][e] + red[1][cg][e] + red[2][cg][e] + red[3][cg][e]);
+    }
+}
+
+}  // namespace
+
+extern "C" int mgen_gelu_new_f32_fwd(const float* h, float* act, long n, hipStream_t stream) {
+    MGEN_REQUIRE(h && act && n > 0 && n % 4 == 0, "mgen_gelu_new_f32_fwd: bad arguments (n must be a multiple of 4)");
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL((gelu_f32_kernel<false>), dim3((unsigned)nb), dim3(256), 0, stream, h, (const float*)nullptr,
+                       act, n / 4);
+    return mgen_check_launch("mgen_gelu_new_f32_fwd");
+}
+
+extern "C" int mgen_gelu_new_f32_bwd(const float* h, const float* dact, float* dh, long n, hipStream_t stream) {
+    MGEN_REQUIRE(h && dact && dh && n > 0 && n % 4 == 0,
+                 "mgen_gelu_new_f32_bwd: bad arguments (n must be a multiple of 4)");
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL((gelu_f32_kernel<true>), dim3((unsigned)nb), dim3(256), 0, stream, h, dact, dh, n / 4);
+    return mgen_check_launch("mgen_gelu_new_f32_bwd");
+}
+
+// y [T][ld] fp32: y[t][n] += bias[n] for n < N (N % 4 == 0, ld % 4 == 0)
+extern "C" int mgen_bias_add_f32(float* y, long ld, const float* bias, long T, int N, hipStream_t stream) {
+    MGEN_REQUIRE(y && bias && T > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && ld >= N,
+                 "mgen_bias_add_f32: bad arguments (N and ld must be multiples of 4)");
+    long nb = (T * (N / 4) + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(bias_add_f32_kernel, dim3((unsigned)nb), dim3(256), 0, stream, y, ld, bias, T, N);
+    return mgen_check_launch("mgen_bias_add_f32");
+}
+
+// out[n] += sum over the T rows of x[t][n] (x fp32 [T][ld])
+extern "C" int mgen_colsum_f32(const float* x, long ld, float* out, long T, int N, hipStream_t stream) {
+    MGEN_REQUIRE(x && out && T > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && ld >= N,
+                 "mgen_colsum_f32: bad arguments (N and ld must be multiples of 4)");
+    const int gx = (N / 4 + 63) / 64;
+    long gy = 1024 / gx;
+    if (gy < 1) gy = 1;
+    long rows = (T + gy - 1) / gy;
+    if (rows < 64) rows = 64;
+    gy = (T + rows - 1) / rows;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, stream, x, ld, out, T, N, rows);
+    return mgen_check_launch("mgen_colsum_f32");
+}

@@ -51,6 +51,10 @@ SIGNATURES = {
     "mgen_swiglu_f32_bwd": [P, P, P, L, I, P],
     "mgen_attn_f32_fwd": [P, P, P, P, P, L, L, L, L, I, I, I, I, I, F, P],
     "mgen_attn_f32_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, P],
+    "mgen_gelu_new_f32_fwd": [P, P, L, P],
+    "mgen_gelu_new_f32_bwd": [P, P, P, L, P],
+    "mgen_bias_add_f32": [P, L, P, L, I, P],
+    "mgen_colsum_f32": [P, L, P, L, I, P],
     "mgen_collate_tokens": [P, P, P, P, P, P, I, I, L, I, P],
     "mgen_collate_pos4d": [P, L, P, P, P, P, P, I, I, P],
     "mgen_notes_to_events": [P, L, F, P, P, P],

@@ -48,13 +48,13 @@ _LAYER_FIELDS = {"ln1w": "ln_1.weight", "ln1b": "ln_1.bias", "attn": "attn.c_att
 
 
 class MidiGPT2LM(MidiLM):
-    def __init__(self, cfg: LMConfig, device="cuda", seed: Optional[int] = 0):
+    def __init__(self, cfg: LMConfig, device="cuda", seed: Optional[int] = 0, compute_dtype=torch.bfloat16):
         if cfg.arch != "gpt2":
             raise ValueError("MidiGPT2LM needs a config with arch='gpt2' (mgen.config.gpt2_decoder())")
         if cfg.hidden_size != cfg.num_attention_heads * cfg.head_dim or \
                 cfg.num_key_value_heads != cfg.num_attention_heads or not cfg.tie_word_embeddings:
             raise ValueError("GPT-2: hidden = heads * head_dim, no grouped keys, tied head")
-        super().__init__(cfg, device=device, seed=seed)
+        super().__init__(cfg, device=device, seed=seed, compute_dtype=compute_dtype)
         self.dropout_seed = int(seed or 0)     # give every data-parallel rank its own
         self._dropout_calls = 0                # training-mode forwards so far
 
@@ -65,6 +65,8 @@ class MidiGPT2LM(MidiLM):
         if not self.training or cache is not None or pos is not None or \
                 (cfg.embd_pdrop == 0 and cfg.resid_pdrop == 0 and cfg.attn_pdrop == 0):
             return None
+        if self.act_dtype == torch.float32:
+            raise NotImplementedError("dropout runs in the bf16-mixed mode only: use eval() or p = 0 in fp32 mode")
         n = 3 * cfg.num_hidden_layers + 1
         base = self._dropout_calls * n
         self._dropout_calls += 1
@@ -83,6 +85,9 @@ class MidiGPT2LM(MidiLM):
         for tag, flat in (("w_", self.flat_param), ("g_", self.flat_grad), ("s_", self.flat_shadow)):
             for short, name in _LAYER_FIELDS.items():
                 setattr(v, tag + short, self._view(flat, p + name))
+        if self.flat_shadow_lo is not None:   # fp32 parity mode: split weights, fp32 biases
+            for short, name in _LAYER_FIELDS.items():
+                setattr(v, "s_" + short, getattr(v, "w_" + short) if short.endswith("_b") else self._w(p + name))
         return v
 
     def _lm_head_name(self):
@@ -124,7 +129,9 @@ class MidiGPT2LM(MidiLM):
         d, H, Dh, I = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.intermediate_size
         if pos is None and S > cfg.max_position_embeddings:
             raise ValueError(f"sequence length {S} exceeds n_positions {cfg.max_position_embeddings}")
-        dev, bf, f32 = input_ids.device, torch.bfloat16, torch.float32
+        dev, bf, f32 = input_ids.device, self.act_dtype, torch.float32
+        full = bf == torch.float32            # fp32 parity mode
+        esz = 4 if full else 2                # bytes per activation element (pointer offsets into qkv)
         eps = cfg.layer_norm_eps
         scale = Dh ** -0.5
         h = torch.empty(T, d, dtype=f32, device=dev)
@@ -153,13 +160,13 @@ class MidiGPT2LM(MidiLM):
             ops.layernorm_fwd(h, v.w_ln1w, v.w_ln1b, x1, mean1, rstd1, eps)
             qkv = torch.empty(T, 3 * d, dtype=bf, device=dev)
             ops.conv1d_fwd(x1, v.s_attn, v.s_attn_b, qkv)
-            qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
+            qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + esz * d, qkv.data_ptr() + 2 * esz * d
             if cache is not None:
                 ops.kv_append(kp, vp, 3 * d, 3 * d, cache.k[l], cache.v[l], cache.zero_pos, B, S, H, Dh,
                               cache.max_len)
             att = torch.empty(T, d, dtype=bf, device=dev)
             lse = torch.empty(B, H, S, dtype=f32, device=dev)
-            ops.attn_fwd(qp, kp, vp, att.data_ptr(), lse, 3 * d, 3 * d, 3 * d, d, B, S, H, H, Dh, scale,
+            ops.attn_fwd(qp, kp, vp, att.data_ptr(), lse, 3 * d, 3 * d, 3 * d, d, B, S, H, H, Dh, scale, f32=full,
                          drop_p=p_a, drop_key=keys[3 * l + 1] if keys else 0)
             h_mid = proj_resid(att, v.s_proj, v.s_proj_b, h, keys[3 * l + 2] if keys else 0)
             x2 = torch.empty(T, d, dtype=bf, device=dev)
@@ -186,7 +193,9 @@ class MidiGPT2LM(MidiLM):
         B, S = input_ids.shape
         T = B * S
         d, H, Dh, I = cfg.hidden_size, cfg.num_attention_heads, cfg.head_dim, cfg.intermediate_size
-        dev, bf, f32 = input_ids.device, torch.bfloat16, torch.float32
+        dev, bf, f32 = input_ids.device, self.act_dtype, torch.float32
+        full = bf == torch.float32
+        esz = 4 if full else 2
         scale = Dh ** -0.5
         h_last, meanN, rstdN, keys = final
         p_e, p_r, p_a = (cfg.embd_pdrop, cfg.resid_pdrop, cfg.attn_pdrop) if keys else (0.0, 0.0, 0.0)
@@ -225,10 +234,10 @@ class MidiGPT2LM(MidiLM):
                 g = dy
             ops.conv1d_dgrad(g, v.s_proj, datt)
             ops.conv1d_wgrad(g, att, v.g_proj, v.g_proj_b)
-            qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + 2 * d, qkv.data_ptr() + 4 * d
-            dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + 2 * d, dqkv.data_ptr() + 4 * d
+            qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + esz * d, qkv.data_ptr() + 2 * esz * d
+            dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + esz * d, dqkv.data_ptr() + 2 * esz * d
             ops.attn_bwd(qp, kp, vp, att.data_ptr(), datt.data_ptr(), lse, delta, dqp, dkp, dvp,
-                         3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, B, S, H, H, Dh, scale,
+                         3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, B, S, H, H, Dh, scale, f32=full,
                          drop_p=p_a, drop_key=keys[3 * l + 1] if keys else 0)
             ops.conv1d_dgrad(dqkv, v.s_attn, dx)
             ops.conv1d_wgrad(dqkv, x1, v.g_attn, v.g_attn_b)

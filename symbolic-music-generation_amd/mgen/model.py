@@ -103,8 +103,8 @@ class MidiLM(GenerationMixin, nn.Module):
         if compute_dtype not in (torch.bfloat16, torch.float32):
             raise NotImplementedError("compute_dtype is torch.bfloat16 (bf16-mixed, the training path) or torch.float32 "
                                       "(parity mode)")
-        if compute_dtype == torch.float32 and (cfg.pos4d or cfg.arch != "llama"):
-            raise NotImplementedError("the fp32 parity mode covers the token models with RMSNorm/RoPE/SwiGLU blocks")
+        if compute_dtype == torch.float32 and cfg.pos4d:
+            raise NotImplementedError("the fp32 parity mode covers the token models (not the 4-D position model)")
         # bf16: what precision="bf16-mixed" computes. fp32: no rounding anywhere; products run on the bf16 MFMA GEMM
         # from operands split into hi + lo halves (three products per GEMM), attention and the gate in plain fp32
         self.act_dtype = compute_dtype

@@ -140,6 +140,11 @@ def conv1d_fwd(x, w, bias, out, out_mode=OUT_BF16, resid=None):
     """out[T,N] = x[T,K] @ w[K,N] + bias[N]  (GPT-2 Conv1D: weight stored [in, out])."""
     T, K = x.shape
     N = w.shape[1]
+    if isinstance(w, W2):   # fp32 parity mode: three bf16 products into an fp32 output, then the fp32 bias
+        gemm_any(x, w, out, T, N, K, x.stride(0), w.stride(0), out.stride(0), False, True, out_mode, resid,
+                 resid.stride(0) if resid is not None else 0)
+        call("mgen_bias_add_f32", _p(out), out.stride(0), _p(bias), T, N, _stream())
+        return
     gemm_bias(x, w, out, bias, T, N, K, x.stride(0), w.stride(0), out.stride(0), False, True, out_mode, resid,
               resid.stride(0) if resid is not None else 0)
 
@@ -148,15 +153,16 @@ def conv1d_dgrad(dy, w, dx):
     """dx[T,K] = dy[T,N] @ w[K,N]^T."""
     T, N = dy.shape
     K = w.shape[0]
-    gemm(dy, w, dx, T, K, N, dy.stride(0), w.stride(0), dx.stride(0), False, False, OUT_BF16)
+    gemm_any(dy, w, dx, T, K, N, dy.stride(0), w.stride(0), dx.stride(0), False, False, OUT_BF16)
 
 
 def conv1d_wgrad(dy, x, dw, db):
     """dw[K,N] += x[T,K]^T @ dy[T,N];  db[N] += column sums of dy."""
     T, N = dy.shape
     K = x.shape[1]
-    gemm(x, dy, dw, K, N, T, x.stride(0), dy.stride(0), dw.stride(0), True, True, OUT_F32_ACC)
-    call("mgen_colsum_bf16", _p(dy), dy.stride(0), _p(db), T, N, _stream())
+    gemm_any(x, dy, dw, K, N, T, x.stride(0), dy.stride(0), dw.stride(0), True, True, OUT_F32_ACC)
+    call("mgen_colsum_f32" if dy.dtype == torch.float32 else "mgen_colsum_bf16", _p(dy), dy.stride(0), _p(db), T, N,
+         _stream())
 
 
 def layernorm_fwd(x, w, b, y, mean, rstd, eps):
@@ -173,12 +179,14 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dres_lp, dw, db, accumulate):
 
 def gelu_new_fwd(h, act):
     _need_gpu(h, act)
-    call("mgen_gelu_new_fwd", _p(h), _p(act), h.numel(), _stream())
+    call("mgen_gelu_new_f32_fwd" if h.dtype == torch.float32 else "mgen_gelu_new_fwd", _p(h), _p(act), h.numel(),
+         _stream())
 
 
 def gelu_new_bwd(h, dact, dh):
     _need_gpu(h, dact, dh)
-    call("mgen_gelu_new_bwd", _p(h), _p(dact), _p(dh), h.numel(), _stream())
+    call("mgen_gelu_new_f32_bwd" if h.dtype == torch.float32 else "mgen_gelu_new_bwd", _p(h), _p(dact), _p(dh),
+         h.numel(), _stream())
 
 
 def embed_pos_fwd(ids, wte, wpe, pos, out, S, err_flag=None):

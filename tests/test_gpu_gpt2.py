@@ -231,3 +231,89 @@ def test_sampled_decode_matches_oracle_on_own_logits(tiny):
         vmin = torch.where(torch.isfinite(warped), s, torch.full_like(s, float("inf"))).min(-1, keepdim=True).values
         warped = torch.where(s == vmin, s, warped)
         assert torch.equal(R.sample_with_noise(warped, noise[t]), out[:, 8 + t]), t
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp32 parity mode (no rounding anywhere): within 1e-4 of the fp32 fixture made from GPT2LMHeadModel
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def tiny32():
+    from mgen.gpt2 import MidiGPT2LM
+    g = load("tiny_gpt2")
+    p = tiny_params_gpt2()
+    m = MidiGPT2LM(_cfg(), device="cuda:0", seed=None, compute_dtype=torch.float32)
+    m.load_state_dict(p)
+    return m, g, p
+
+
+def test_fp32_mode_logits_loss_grads(tiny32):
+    m, g, p = tiny32
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    logits = m(input_ids=ids).logits
+    assert logits.dtype == torch.float32
+    assert rel_err(slim(logits.cpu().numpy()), g["fp32_logits"]) < FP32_TOL
+    m.zero_grad()
+    out = m(input_ids=ids, labels=ids)
+    out.loss.backward()
+    assert abs(float(out.loss.detach()) - float(g["fp32_loss"])) < FP32_TOL * abs(float(g["fp32_loss"]))
+    grads = {n: q.grad.detach().float().cpu().numpy() for n, q in m.named_parameters()}
+    worst = {}
+    for k in g.files:
+        if k.startswith("fp32_grad/"):
+            name = k.split("/", 1)[1]
+            worst[name] = rel_err(slim(grads[name]), g[k])
+    print({k: float("%.2e" % v) for k, v in worst.items()})
+    assert max(worst.values()) < FP32_TOL, worst
+    seen = {id(q): q for q in m.parameters()}      # (the tied head is one tensor)
+    gn = float(np.sqrt(sum(float((q.grad.double() ** 2).sum()) for q in seen.values())))
+    assert abs(gn - float(g["fp32_grad_norm"])) < FP32_TOL * float(g["fp32_grad_norm"])
+    # padded batch
+    m.zero_grad()
+    out = m(input_ids=ids, attention_mask=torch.from_numpy(g["pad_mask"]).cuda(),
+            labels=torch.from_numpy(g["pad_labels"]).cuda())
+    out.loss.backward()
+    assert abs(float(out.loss.detach()) - float(g["pad_loss"])) < FP32_TOL * abs(float(g["pad_loss"]))
+    for k in g.files:
+        if k.startswith("pad_grad/"):
+            name = k.split("/", 1)[1]
+            gq = dict(m.named_parameters())[name].grad.detach().float().cpu().numpy()
+            assert rel_err(slim(gq), g[k]) < FP32_TOL, name
+
+
+def test_fp32_mode_training_curve_and_greedy_tokens():
+    from mgen import get_optim
+    from mgen.gpt2 import MidiGPT2LM
+    g = load("tiny_gpt2")
+    m = MidiGPT2LM(_cfg(), device="cuda:0", seed=None, compute_dtype=torch.float32)
+    m.load_state_dict(tiny_params_gpt2())
+    want = torch.from_numpy(g["greedy_tokens"])
+    got = m.generate(want[:, :8].cuda(), max_new_tokens=256, do_sample=False).cpu()
+    same = (got == want)[0, 8:].numpy()
+    if not same.all():
+        first_bad = int(np.argmin(same))
+        assert g["greedy_margin"][first_bad] < 1e-4, (first_bad, g["greedy_margin"][first_bad])
+    ids = torch.from_numpy(g["input_ids"]).cuda()
+    opt, sched = get_optim(m, 3e-4, 12, 20, warmup=10, max_grad_norm=1.0)
+    losses = []
+    for step in range(14):
+        opt.zero_grad()
+        loss = m(input_ids=ids, labels=ids).loss
+        loss.backward()
+        opt.step()
+        sched.step()
+        losses.append(float(loss.detach()))
+    np.testing.assert_allclose(losses, g["train_losses"], rtol=2e-4)
+
+
+def test_fp32_mode_refuses_dropout():
+    from mgen.config import LMConfig
+    from mgen.gpt2 import MidiGPT2LM
+    kw = {k: getattr(OCFG, k) for k in R.LMConfig.__dataclass_fields__}
+    m = MidiGPT2LM(LMConfig(arch="gpt2", resid_pdrop=0.1, **kw), device="cuda:0", seed=0, compute_dtype=torch.float32)
+    ids = torch.randint(3, OCFG.vocab_size, (1, 64)).cuda()
+    with pytest.raises(NotImplementedError):
+        m(input_ids=ids, labels=ids)
+    m.eval()
+    assert np.isfinite(float(m(input_ids=ids, labels=ids).loss))
