@@ -300,7 +300,7 @@ class GenerationMixin:
             ops.pos4d_next(pred, ld_pred, out.data_ptr() + row_bytes * t, ld, out.data_ptr() + row_bytes * (t + 1),
                            ld, B)
 
-        if not use_cache:
+        if not use_cache or getattr(self, "act_dtype", torch.bfloat16) == torch.float32:
             for i in range(total_length):
                 t = P + i - 1
                 xN, _ = self._run_layers(out[:, :t + 1].contiguous(), save=None)

@@ -103,8 +103,6 @@ class MidiLM(GenerationMixin, nn.Module):
         if compute_dtype not in (torch.bfloat16, torch.float32):
             raise NotImplementedError("compute_dtype is torch.bfloat16 (bf16-mixed, the training path) or torch.float32 "
                                       "(parity mode)")
-        if compute_dtype == torch.float32 and cfg.pos4d:
-            raise NotImplementedError("the fp32 parity mode covers the token models (not the 4-D position model)")
         # bf16: what precision="bf16-mixed" computes. fp32: no rounding anywhere; products run on the bf16 MFMA GEMM
         # from operands split into hi + lo halves (three products per GEMM), attention and the gate in plain fp32
         self.act_dtype = compute_dtype
@@ -394,9 +392,10 @@ class MidiLM(GenerationMixin, nn.Module):
         cfg = self.cfg
         T, d = xN.shape[0], cfg.hidden_size
         dev = xN.device
-        W = self._view(self.flat_shadow, "lm_head.weight")
-        pairs = torch.empty(T, POS4D_HEAD_OUT, dtype=torch.bfloat16, device=dev)
-        ops.gemm(xN, W, pairs, T, POS4D_HEAD_OUT, d, xN.stride(0), W.stride(0), POS4D_HEAD_OUT)
+        W = self._w("lm_head.weight")
+        xN = ops.presplit(xN)
+        pairs = torch.empty(T, POS4D_HEAD_OUT, dtype=self.act_dtype, device=dev)
+        ops.gemm_any(xN, W, pairs, T, POS4D_HEAD_OUT, d, xN.stride(0), W.stride(0), POS4D_HEAD_OUT)
         pred = torch.empty(T, POS4D_HEAD_OUT, dtype=torch.float32, device=dev)
         self._last_pred = pred
         if labels is None:
@@ -405,19 +404,20 @@ class MidiLM(GenerationMixin, nn.Module):
         inv_count = torch.empty(1, dtype=torch.float32, device=dev)
         ops.cos4d_count(labels, inv_count)
         row_loss = torch.empty(T, dtype=torch.float32, device=dev)
-        dpairs = torch.empty(T, POS4D_HEAD_OUT, dtype=torch.bfloat16, device=dev) if with_grad else None
+        dpairs = torch.empty(T, POS4D_HEAD_OUT, dtype=self.act_dtype, device=dev) if with_grad else None
         ops.cos4d_fwd_bwd(pairs, labels, inv_count, 1.0, pred, row_loss, dpairs)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         ops.ce_finalize(row_loss, inv_count, loss)
         dxN = None
         if with_grad:
-            dxN = torch.empty(T, d, dtype=torch.bfloat16, device=dev)
-            ops.gemm(dpairs, W, dxN, T, d, POS4D_HEAD_OUT, POS4D_HEAD_OUT, W.stride(0), d, False, True, ops.OUT_BF16)
+            dxN = torch.empty(T, d, dtype=self.act_dtype, device=dev)
+            dps = ops.presplit(dpairs)
+            ops.gemm_any(dps, W, dxN, T, d, POS4D_HEAD_OUT, POS4D_HEAD_OUT, W.stride(0), d, False, True, ops.OUT_BF16)
             if self._lm_grad_tmp is None:
                 self._lm_grad_tmp = torch.empty(POS4D_HEAD_OUT, d, dtype=torch.float32, device=dev)
             self._lm_grad_tmp.zero_()   # accumulate mode lets the [16, d] output use the split-K path over T
-            ops.gemm(dpairs, xN, self._lm_grad_tmp, POS4D_HEAD_OUT, d, T, POS4D_HEAD_OUT, xN.stride(0), d, True, True,
-                     ops.OUT_F32_ACC)
+            ops.gemm_any(dps, xN, self._lm_grad_tmp, POS4D_HEAD_OUT, d, T, POS4D_HEAD_OUT, xN.stride(0), d, True, True,
+                         ops.OUT_F32_ACC)
         return loss, dxN
 
     def _head_loss(self, xN, labels, with_grad: bool):
@@ -471,10 +471,10 @@ class MidiLM(GenerationMixin, nn.Module):
             if cfg.pos4d:
                 # q, k (normalised) and v all rotated: one [T, NQ] buffer in the layout of qkv
                 qk = torch.empty(T, NQ, dtype=bf, device=dev)
-                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qk.data_ptr() + 2 * QK
+                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qk.data_ptr() + esz * QK
                 sq = sk = sv = NQ
                 ops.qkvnorm_rope4d_fwd(qkv.data_ptr(), NQ, qp, kp, vp, NQ, NQ, NQ, v.w_qn, v.w_kn, cs, T, H, KVH, KVH,
-                                       Dh, cfg.rms_norm_eps)
+                                       Dh, cfg.rms_norm_eps, is_bf16=not f32)
             else:
                 qk = torch.empty(T, QK, dtype=bf, device=dev)
                 qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qkv.data_ptr() + esz * QK
@@ -632,7 +632,7 @@ class MidiLM(GenerationMixin, nn.Module):
             if cfg.pos4d:
                 # datt is the gradient of the rotated-back output: rotate it forward to reach the attention output
                 ops.rotate4d(datt, datt, cs, T, H, Dh, inverse=False)
-                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + 2 * H * Dh, qk.data_ptr() + 2 * QK
+                qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qk.data_ptr() + esz * QK
                 sq = sk = sv = NQ
             else:
                 qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qkv.data_ptr() + esz * QK
@@ -641,7 +641,7 @@ class MidiLM(GenerationMixin, nn.Module):
                          sq, sk, sv, H * Dh, H * Dh, NQ, NQ, NQ, B, S, H, KVH, Dh, scale, f32=f32)
             if cfg.pos4d:
                 ops.qkvnorm_rope4d_bwd(dqp, NQ, dqp, dkp, dvp, NQ, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn,
-                                       cs, T, H, KVH, KVH, Dh, cfg.rms_norm_eps)
+                                       cs, T, H, KVH, KVH, Dh, cfg.rms_norm_eps, is_bf16=not f32)
             else:
                 ops.qknorm_rope_bwd(dqp, NQ, dqp, dkp, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn, cs, None, S,
                                     T, H, KVH, Dh, cfg.rms_norm_eps, is_bf16=not f32)

@@ -297,3 +297,39 @@ def test_generate_music_batch_of_streams(tiny):
     assert torch.equal(rows[:, :5], prompt)
     solo = m.generate_music(prompt[1:2], 12)
     np.testing.assert_allclose(rows[1].cpu().numpy(), solo[0].cpu().numpy(), rtol=1e-3, atol=1e-2)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fp32 parity mode: within 1e-4 of the fp32 outputs of the reference's own module
+def test_fp32_mode_matches_the_reference_module():
+    from mgen import MidiLM
+    g = load("tiny_pos4d")
+    m = MidiLM(_cfg(), device="cuda:0", seed=None, compute_dtype=torch.float32)
+    m.load_state_dict(tiny_params_pos4d())
+    pos = torch.from_numpy(g["position_tensors"]).cuda()
+    lab = torch.from_numpy(g["labels"]).cuda()
+    mask = torch.from_numpy(g["attention_mask"]).cuda()
+    with torch.no_grad():
+        pred = m(position_tensors=pos).logits.float().cpu().numpy()
+    assert rel_err(pred, g["fp32_pred"]) < 1e-4
+    m.zero_grad()
+    out = m(position_tensors=pos, attention_mask=mask, labels=lab)
+    out.loss.backward()
+    assert abs(float(out.loss.detach()) - float(g["fp32_loss"])) < 1e-4 * abs(float(g["fp32_loss"]))
+    grads = {n: q.grad.detach().float().cpu().numpy() for n, q in m.named_parameters()}
+    worst = {}
+    for k in g.files:
+        if k.startswith("fp32_grad/"):
+            name = k.split("/", 1)[1]
+            worst[name] = rel_err(grads[name], g[k])
+    print({k: float("%.2e" % v) for k, v in worst.items()})
+    assert max(worst.values()) < 1e-4, worst
+    # the reference's generated rows, teacher-forced, and cache-less generation
+    rows = torch.from_numpy(g["gen_rows"])[None, :48].cuda()
+    with torch.no_grad():
+        pr = m(position_tensors=rows).logits[0].float().cpu().numpy()
+    assert rel_err(pr, g["gen_preds"]) < 1e-4
+    gen, preds = m.generate_music(rows[:, :1], 6, return_preds=True)      # (no KV cache in this mode)
+    assert tuple(gen.shape) == (1, 7, 4)
+    assert rel_err(preds[0, 0].cpu().numpy(), g["gen_preds"][0]) < 1e-4
+    np.testing.assert_allclose(gen[0, 1].cpu().numpy(), g["gen_rows"][1], rtol=1e-4, atol=1e-3)
