@@ -40,6 +40,14 @@ int mgen_device_info(int device, char* name, int name_len);
 int mgen_gemm_bf16(const void* A, const void* B, void* C, const void* resid, int M, int N, int K, long lda, long ldb,
                    long ldc, long ldr, int transA, int transB, int out_mode, float alpha, mgen_stream_t stream);
 
+/* C = [A | A2] [B | B2]^T in one accumulator: the reduction runs over K indices of (A, B), then K2 of (A2, B2). A
+ * projection with a low-rank adapter in one launch - peft's Linear.forward, base(x) + lora_B(lora_A(x)) * scaling
+ * (reference src/model/model.py:251-271): y = x W^T + t B^T with t = scaling * x A^T, and its input gradient
+ * dx = dy W + dt A (transB = 1: B = W stored [K][N], B2 = adapter A stored [K2][N]). A, A2 row-major; K, K2 multiples
+ * of 64 (the rank is padded with zero columns / rows); out_mode 0, 1, 3 or 4. */
+int mgen_gemm_bf16_seg(const void* A, const void* B, const void* A2, const void* B2, void* C, const void* resid, int M,
+                       int N, int K, int K2, long lda, long ldb, long lda2, long ldb2, long ldc, long ldr, int transB,
+                       int out_mode, mgen_stream_t stream);
 /* Split-K without atomics for products with few output tiles (the decode path: M = number of streams). The K range
  * is cut into nslabs slices (mgen_gemm_slab_count(K, max_slabs) gives a valid count: 128 reduction indices per slice,
  * more when that would exceed max_slabs); slice z stores its fp32 partial product [M][N] at slabs + z*M*N.

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MGEN_LIB") or os.path.join(_HERE, "libmgen_hip.so")
 # name -> argument types (every function returns int, 0 = ok), in the order of include/mgen.h
 SIGNATURES = {
     "mgen_gemm_bf16": [P, P, P, P, I, I, I, L, L, L, L, I, I, I, F, P],
+    "mgen_gemm_bf16_seg": [P, P, P, P, P, P, I, I, I, I, L, L, L, L, L, L, I, I, P],
     "mgen_gemm_bf16_slabs": [P, P, P, I, I, I, L, L, I, I, I, P],
     "mgen_slab_resid_rmsnorm": [P, I, L, P, P, P, P, L, I, F, I, P],
     "mgen_rmsnorm_fwd": [P, P, P, P, L, I, F, I, P],

@@ -85,6 +85,15 @@ def gemm_any(a, b, c, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_
     gemm(al, bh, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, OUT_F32_ACC)
 
 
+def gemm_seg(a, b, a2, b2, c, M, N, K, K2, lda, ldb, lda2, ldb2, ldc, trans_b=False, out_mode=OUT_BF16, resid=None,
+             ldr=0):
+    """c = [a | a2] [b | b2]^T: one launch for a projection plus its low-rank adapter product (K, K2 multiples of
+    64). trans_b: b stored [K, N] and b2 stored [K2, N]."""
+    _need_gpu(a, b, a2, b2, c)
+    call("mgen_gemm_bf16_seg", _p(a), _p(b), _p(a2), _p(b2), _p(c), _p(resid), M, N, K, K2, lda, ldb, lda2, ldb2, ldc,
+         ldr, int(trans_b), out_mode, _stream())
+
+
 def gemm_slab_count(K, max_slabs=16):
     from ._lib import lib
     return lib().mgen_gemm_slab_count(K, max_slabs)

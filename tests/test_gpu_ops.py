@@ -428,3 +428,43 @@ def test_cast_scale_axpy(ops):
     assert rel(y, 1 + x) < 1e-6
     ops.scale_bf16_(o, 1.0, a)
     assert rel(o.float(), bf(x).float() * 0.5) < 1e-2
+
+
+@pytest.mark.parametrize("M,N,K,K2,tb", [(300, 200, 128, 64, False), (16500, 2040, 512, 64, False),
+                                         (33000, 1096, 64, 64, True), (1000, 512, 1024, 128, True)])
+def test_gemm_two_operand_pairs(ops, M, N, K, K2, tb):
+    """C = [A | A2] [B | B2]^T in one launch (a projection plus its low-rank adapter product); 128x128, 128x256 and
+    256x256 tiles, ragged edges, both layouts of the B side, residual epilogue."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g) * 0.5)
+    A2 = bf(torch.randn(M, K2, generator=g) * 0.5)
+    B = bf(torch.randn(N, K, generator=g) * 0.5)
+    B2 = bf(torch.randn(N, K2, generator=g) * 0.5)
+    ref = A.float() @ B.float().t() + A2.float() @ B2.float().t()
+    ldn = (N + 7) // 8 * 8
+    def side(mat):   # stored [N][k] or, transposed, [k][ldn]
+        if not tb:
+            return mat.contiguous().to(dev())
+        out = torch.zeros(mat.shape[1], ldn, dtype=torch.bfloat16)
+        out[:, :N] = mat.t()
+        return out.to(dev())
+    b_st, b2_st = side(B), side(B2)
+    ldc = ldn + 8
+    c = torch.full((M, ldc), 3.0, dtype=torch.bfloat16, device=dev())
+    ops.gemm_seg(A.to(dev()), b_st, A2.to(dev()), b2_st, c, M, N, K, K2, K, b_st.stride(0), K2, b2_st.stride(0), ldc,
+                 tb, ops.OUT_BF16)
+    assert rel(c[:, :N].float(), ref) < 1e-2
+    assert bool((c[:, N:] == 3.0).all()), "wrote outside the N columns"
+    res = torch.randn(M, N, generator=g)
+    out = torch.empty(M, N, dtype=torch.float32, device=dev())
+    ops.gemm_seg(A.to(dev()), b_st, A2.to(dev()), b2_st, out, M, N, K, K2, K, b_st.stride(0), K2, b2_st.stride(0), N,
+                 tb, ops.OUT_F32_RESID_BF16ROUND, res.to(dev()), N)
+    assert rel(out, res + bf(ref).float()) < 1e-2
+    # the plain entry point is untouched by the second build of the kernels
+    c2 = torch.empty(M, ldc, dtype=torch.float32, device=dev())
+    ops.gemm(A.to(dev()), b_st, c2, M, N, K, K, b_st.stride(0), ldc, False, tb, ops.OUT_F32)
+    assert rel(c2[:, :N], A.float() @ B.float().t()) < 2e-5
+    from mgen._lib import MgenError
+    with pytest.raises(MgenError):   # reduction lengths must be multiples of 64
+        ops.gemm_seg(A.to(dev()), b_st, A2.to(dev()), b2_st, c, M, N, K, 32, K, b_st.stride(0), K2, b2_st.stride(0),
+                     ldc, tb, ops.OUT_BF16)
