@@ -9,10 +9,12 @@ dropout (`dropout=`, training mode only) masks the adapter's input with a hash o
 every forward has its own key and the backward pass recomputes the masks, as peft's per-layer Dropout modules draw
 independent masks. With dropout on, the gate and up adapters no longer share one product (their inputs differ).
 
-Here the adapters live in one small flat fp32 buffer (+ gradient, + bf16 shadow) next to the frozen model. Each site
-costs two extra products in the forward pass, t = s * x A^T (N = r) and y += t B^T (K = r, added straight into the
-base projection's output by the GEMM epilogue), and four in the backward pass (dt = s * dy B, dB += dy^T t,
-dA += dt^T x, dx += dt A); the base weights get no gradient products at all.
+Here the adapters live in one small flat fp32 buffer (+ gradient, + bf16 shadow) next to the frozen model. Without
+dropout a site's forward is t = s * x A^T (N = r) and then ONE product y = [x | t] [W | B]^T whose reduction runs over
+the base weight and then over the adapter (`mgen_gemm_bf16_seg`; the rank is padded to 64 with zeros); its backward
+is dt = s * dy B, dB += dy^T t, dA += dt^T x and ONE product dx = [dy | dt] [W ; A]. With dropout the adapter sees a
+masked input, so its products stay separate (y += t B^T through the accumulate epilogue, dx += dropout'(dt A)).
+The base weights get no gradient products at all.
 """
 import math
 
@@ -21,6 +23,10 @@ import torch
 from . import ops
 
 SITES = ("qkv", "o", "gate", "up", "down")
+
+
+def _up64(n):
+    return (n + 63) // 64 * 64
 _NAMES = {"qkv": "self_attn.qkv_proj", "o": "self_attn.o_proj", "gate": "mlp.gate_proj", "up": "mlp.up_proj",
           "down": "mlp.down_proj"}
 
@@ -77,6 +83,16 @@ class LoraAdapters:
             # [A_gate; A_up] as one [2r, d] operand (the two blocks are adjacent in the flat buffers)
             sites["gu_sA"] = self.flat_shadow[sites["gate"].sA.storage_offset():][:2 * r * d].view(2 * r, d)
             sites["gu_gA"] = self.flat_grad[sites["gate"].gA.storage_offset():][:2 * r * d].view(2 * r, d)
+            # zero-padded bf16 operands of the two-pair products: B as [out, Rp], A as [Rp, in]; gate and up share
+            # one pair (block-diagonal B over [gate | up] outputs, [A_gate; A_up] stacked)
+            Rp, Rp2 = _up64(r), _up64(2 * r)
+            bf = torch.bfloat16
+            pad = {}
+            for k in ("qkv", "o", "down"):
+                i, o = self.dims[k]
+                pad[k] = (torch.zeros(Rp, i, dtype=bf, device=dev), torch.zeros(o, Rp, dtype=bf, device=dev))
+            pad["gu"] = (torch.zeros(Rp2, d, dtype=bf, device=dev), torch.zeros(2 * I, Rp2, dtype=bf, device=dev))
+            sites["pad"] = pad
             self.layers.append(sites)
         # a differentiable input for the model's autograd node while every base parameter is frozen
         self.anchor = torch.nn.Parameter(self.flat_param[:8])
@@ -85,10 +101,26 @@ class LoraAdapters:
     def sync_shadow(self):
         if self._shadow_version != self.flat_param._version:
             ops.cast(self.flat_param, self.flat_shadow)
+            self._refresh_padded()
             self._shadow_version = self.flat_param._version
 
     def mark_shadow_fresh(self):
+        """The fused optimizer has rewritten master and bf16 shadow in one kernel."""
+        self._refresh_padded()
         self._shadow_version = self.flat_param._version
+
+    def _refresh_padded(self):
+        r = self.r
+        I = self.dims["gate"][1]
+        for st in self.layers:
+            for k in ("qkv", "o", "down"):
+                pA, pB = st["pad"][k]
+                pA[:r].copy_(st[k].sA)
+                pB[:, :r].copy_(st[k].sB)
+            pA, pB = st["pad"]["gu"]
+            pA[:2 * r].copy_(st["gu_sA"])
+            pB[:I, :r].copy_(st["gate"].sB)
+            pB[I:, r:2 * r].copy_(st["up"].sB)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -129,6 +161,64 @@ class LoraAdapters:
         xd = self._buf(x)
         ops.dropout(x, xd, self.dropout_p, key)
         return xd
+
+    # ---- one site, adapter folded into the base product ------------------------------------------------------
+    def fwd_fused(self, x, W, st, k, y, n_in, n_out, out_mode=ops.OUT_BF16, resid=None, key=None):
+        """y = x W^T + (s dropout(x) A^T) B^T (+ resid) in two launches; returns t = s dropout(x) A^T as [T, Rp]
+        (zero beyond r). key: the site's dropout key, None = no dropout."""
+        T, r = x.shape[0], self.r
+        pA, pB = st["pad"][k]
+        Rp = pB.shape[1]
+        t = (torch.zeros if Rp != r else torch.empty)(T, Rp, dtype=torch.bfloat16, device=x.device)
+        xin = self._dropped(x, key) if key is not None else x
+        ops.gemm(xin, st[k].sA, t, T, r, n_in, xin.stride(0), st[k].sA.stride(0), Rp, alpha=self.scale)
+        ops.gemm_seg(x, W, t, pB, y, T, n_out, n_in, Rp, x.stride(0), W.stride(0), Rp, Rp, y.stride(0), False, out_mode,
+                     resid, resid.stride(0) if resid is not None else 0)
+        return t
+
+    def fwd_fused_gu(self, x, W, st, gu, d, I, keys=(None, None)):
+        """[gate | up] = x [Wg; Wu]^T + [t_g B_g^T | t_u B_u^T]; returns [t_g | t_u] as [T, Rp2]. keys: the dropout
+        keys of the gate and up adapters (their inputs are then masked independently)."""
+        T, r = x.shape[0], self.r
+        pA, pB = st["pad"]["gu"]
+        Rp2 = pB.shape[1]
+        t = (torch.zeros if Rp2 != 2 * r else torch.empty)(T, Rp2, dtype=torch.bfloat16, device=x.device)
+        if keys[0] is None:
+            ops.gemm(x, st["gu_sA"], t, T, 2 * r, d, x.stride(0), st["gu_sA"].stride(0), Rp2, alpha=self.scale)
+        else:
+            for j, k in enumerate(("gate", "up")):
+                xin = self._dropped(x, keys[j])
+                ops.gemm(xin, st[k].sA, t[:, j * r:(j + 1) * r], T, r, d, xin.stride(0), st[k].sA.stride(0), Rp2,
+                         alpha=self.scale)
+        ops.gemm_seg(x, W, t, pB, gu, T, 2 * I, d, Rp2, x.stride(0), W.stride(0), Rp2, Rp2, gu.stride(0))
+        return t
+
+    def bwd_fused(self, dy, x, t, W, st, k, dx, n_in, n_out):
+        """Adapter gradients of site k and dx = dy W + (s dy B) A in one product (dx is overwritten)."""
+        T, r = dy.shape[0], self.r
+        site = st[k]
+        pA, pB = st["pad"][k]
+        Rp = pA.shape[0]
+        dt = (torch.zeros if Rp != r else torch.empty)(T, Rp, dtype=torch.bfloat16, device=dy.device)
+        ops.gemm(dy, site.sB, dt, T, r, n_out, dy.stride(0), site.sB.stride(0), Rp, trans_b=True, alpha=self.scale)
+        ops.gemm(dy, t, site.gB, n_out, r, T, dy.stride(0), t.stride(0), site.gB.stride(0), True, True, ops.OUT_F32_ACC)
+        ops.gemm(dt, x, site.gA, r, n_in, T, Rp, x.stride(0), site.gA.stride(0), True, True, ops.OUT_F32_ACC)
+        ops.gemm_seg(dy, W, dt, pA, dx, T, n_in, n_out, Rp, dy.stride(0), W.stride(0), Rp, pA.stride(0), dx.stride(0),
+                     True, ops.OUT_BF16)
+
+    def bwd_fused_gu(self, dgu, x, t, W, st, dx, d, I):
+        T, r = dgu.shape[0], self.r
+        pA, pB = st["pad"]["gu"]
+        Rp2 = pA.shape[0]
+        dt = (torch.zeros if Rp2 != 2 * r else torch.empty)(T, Rp2, dtype=torch.bfloat16, device=dgu.device)
+        for j, k in enumerate(("gate", "up")):
+            dy, site = dgu[:, j * I:(j + 1) * I], st[k]
+            dtj, tj = dt[:, j * r:(j + 1) * r], t[:, j * r:(j + 1) * r]
+            ops.gemm(dy, site.sB, dtj, T, r, I, dy.stride(0), site.sB.stride(0), Rp2, trans_b=True, alpha=self.scale)
+            ops.gemm(dy, tj, site.gB, I, r, T, dy.stride(0), Rp2, site.gB.stride(0), True, True, ops.OUT_F32_ACC)
+        ops.gemm(dt, x, st["gu_gA"], 2 * r, d, T, Rp2, x.stride(0), st["gu_gA"].stride(0), True, True, ops.OUT_F32_ACC)
+        ops.gemm_seg(dgu, W, dt, pA, dx, T, d, 2 * I, Rp2, dgu.stride(0), W.stride(0), Rp2, pA.stride(0), dx.stride(0),
+                     True, ops.OUT_BF16)
 
     # ---- one site ------------------------------------------------------------------------------------------
     def fwd(self, x, sA, sB, y, n_in, n_out, key=None, t=None):

@@ -465,9 +465,11 @@ class MidiLM(GenerationMixin, nn.Module):
             rstd1 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h, v.w_ln1, x1, rstd1, cfg.rms_norm_eps)
             qkv = torch.empty(T, NQ, dtype=bf, device=dev)
-            ops.linear_fwd(x1, v.s_qkv, qkv)
-            if la is not None:   # adapters: y += s (x A^T) B^T, added into the base projection's output
-                t_qkv = lo.fwd(x1, la["qkv"].sA, la["qkv"].sB, qkv, d, NQ, key=lk[0])
+            fused = la is not None   # adapters: y = [x | t] [W | B]^T, t = s dropout(x) A^T
+            if fused:
+                t_qkv = lo.fwd_fused(x1, v.s_qkv, la, "qkv", qkv, d, NQ, key=lk[0])
+            else:
+                ops.linear_fwd(x1, v.s_qkv, qkv)
             if cfg.pos4d:
                 # q, k (normalised) and v all rotated: one [T, NQ] buffer in the layout of qkv
                 qk = torch.empty(T, NQ, dtype=bf, device=dev)
@@ -491,28 +493,26 @@ class MidiLM(GenerationMixin, nn.Module):
                 att_o = torch.empty(T, H * Dh, dtype=bf, device=dev)
                 ops.rotate4d(att, att_o, cs, T, H, Dh, inverse=True)
             h_mid = torch.empty(T, d, dtype=torch.float32, device=dev)
-            ops.linear_fwd(att_o, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
-            if la is not None:
-                t_o = lo.fwd(att_o, la["o"].sA, la["o"].sB, h_mid, H * Dh, d, key=lk[1])
+            if fused:
+                t_o = lo.fwd_fused(att_o, v.s_o, la, "o", h_mid, H * Dh, d, ops.OUT_F32_RESID_BF16ROUND, h, key=lk[1])
+            else:
+                ops.linear_fwd(att_o, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
             x2 = torch.empty(T, d, dtype=bf, device=dev)
             rstd2 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h_mid, v.w_ln2, x2, rstd2, cfg.rms_norm_eps)
             gu = torch.empty(T, 2 * I, dtype=bf, device=dev)
-            ops.linear_fwd(x2, v.s_gu, gu)
-            if la is not None and lk[2] is None:   # one product with [A_gate; A_up], then each half through its own B
-                t_gu = lo.fwd(x2, la["gu_sA"], None, None, d, 0)
-                lo.add_out(t_gu[:, :lo.r], la["gate"].sB, gu[:, :I], I)
-                lo.add_out(t_gu[:, lo.r:], la["up"].sB, gu[:, I:], I)
-            elif la is not None:   # dropout: the two adapters see differently masked inputs
-                t_gu = torch.empty(T, 2 * lo.r, dtype=bf, device=dev)
-                lo.fwd(x2, la["gate"].sA, la["gate"].sB, gu[:, :I], d, I, key=lk[2], t=t_gu[:, :lo.r])
-                lo.fwd(x2, la["up"].sA, la["up"].sB, gu[:, I:], d, I, key=lk[3], t=t_gu[:, lo.r:])
+            if fused:   # t = [t_gate | t_up], then one product with the block-diagonal [B_gate, B_up] behind [Wg; Wu]
+                t_gu = lo.fwd_fused_gu(x2, v.s_gu, la, gu, d, I, keys=(lk[2], lk[3]))
+            else:
+                ops.linear_fwd(x2, v.s_gu, gu)
             act = torch.empty(T, I, dtype=bf, device=dev)
             ops.swiglu_fwd(gu, act)
             h_out = torch.empty(T, d, dtype=torch.float32, device=dev)
-            ops.linear_fwd(act, v.s_down, h_out, ops.OUT_F32_RESID_BF16ROUND, h_mid)
-            if la is not None:
-                t_down = lo.fwd(act, la["down"].sA, la["down"].sB, h_out, I, d, key=lk[4])
+            if fused:
+                t_down = lo.fwd_fused(act, v.s_down, la, "down", h_out, I, d, ops.OUT_F32_RESID_BF16ROUND, h_mid,
+                                      key=lk[4])
+            else:
+                ops.linear_fwd(act, v.s_down, h_out, ops.OUT_F32_RESID_BF16ROUND, h_mid)
             if save is not None:
                 save.append((h, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o,
                              (t_qkv, t_o, t_gu, t_down, lk) if la is not None else None))
@@ -603,29 +603,39 @@ class MidiLM(GenerationMixin, nn.Module):
             v = self._layers[l]
             h_in, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o, lts = saved[l]
             la = lo.layers[l] if lo is not None else None   # adapters: the base weights are frozen (no wgrad)
+            fused = la is not None and lts[4][0] is None   # adapters without dropout (as in the forward pass)
             # ---- MLP branch
-            ops.linear_dgrad(dh_lp, v.s_down, dact)
+            if fused:
+                lo.bwd_fused(dh_lp, act, lts[3], v.s_down, la, "down", dact, I, d)
+            else:
+                ops.linear_dgrad(dh_lp, v.s_down, dact)
             if la is None:
                 ops.linear_wgrad(dh_lp, act, v.g_down)
-            else:
+            elif not fused:
                 lo.bwd(dh_lp, act, lts[3], la["down"].sA, la["down"].sB, la["down"].gA, la["down"].gB, dact, I, d,
                        key=lts[4][4])
             ops.swiglu_bwd(gu, dact, dgu)
-            ops.linear_dgrad(dgu, v.s_gu, dx)
+            if fused:
+                lo.bwd_fused_gu(dgu, x2, lts[2], v.s_gu, la, dx, d, I)
+            else:
+                ops.linear_dgrad(dgu, v.s_gu, dx)
             if la is None:
                 ops.linear_wgrad(dgu, x2, v.g_gu)
-            else:
+            elif not fused:
                 r_ = lo.r
                 lo.bwd(dgu[:, :I], x2, lts[2][:, :r_], la["gate"].sA, la["gate"].sB, la["gate"].gA, la["gate"].gB,
                        dx, d, I, key=lts[4][2])
-                lo.bwd(dgu[:, I:], x2, lts[2][:, r_:], la["up"].sA, la["up"].sB, la["up"].gA, la["up"].gB, dx, d, I,
+                lo.bwd(dgu[:, I:], x2, lts[2][:, r_:2 * r_], la["up"].sA, la["up"].sB, la["up"].gA, la["up"].gB, dx, d, I,
                        key=lts[4][3])
             ops.rmsnorm_bwd(dx, h_mid, v.w_ln2, rstd2, dh, dh_lp, v.g_ln2, accumulate=True)
             # ---- attention branch
-            ops.linear_dgrad(dh_lp, v.s_o, datt)
+            if fused:
+                lo.bwd_fused(dh_lp, att_o, lts[1], v.s_o, la, "o", datt, H * Dh, d)
+            else:
+                ops.linear_dgrad(dh_lp, v.s_o, datt)
             if la is None:
                 ops.linear_wgrad(dh_lp, att_o, v.g_o)
-            else:
+            elif not fused:
                 lo.bwd(dh_lp, att_o, lts[1], la["o"].sA, la["o"].sB, la["o"].gA, la["o"].gB, datt, H * Dh, d,
                        key=lts[4][1])
             dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + esz * H * Dh, dqkv.data_ptr() + esz * QK
@@ -645,10 +655,13 @@ class MidiLM(GenerationMixin, nn.Module):
             else:
                 ops.qknorm_rope_bwd(dqp, NQ, dqp, dkp, NQ, NQ, qkv, NQ, v.w_qn, v.w_kn, v.g_qn, v.g_kn, cs, None, S,
                                     T, H, KVH, Dh, cfg.rms_norm_eps, is_bf16=not f32)
-            ops.linear_dgrad(dqkv, v.s_qkv, dx)
+            if fused:
+                lo.bwd_fused(dqkv, x1, lts[0], v.s_qkv, la, "qkv", dx, d, NQ)
+            else:
+                ops.linear_dgrad(dqkv, v.s_qkv, dx)
             if la is None:
                 ops.linear_wgrad(dqkv, x1, v.g_qkv)
-            else:
+            elif not fused:
                 lo.bwd(dqkv, x1, lts[0], la["qkv"].sA, la["qkv"].sB, la["qkv"].gA, la["qkv"].gB, dx, d, NQ,
                        key=lts[4][0])
             ops.rmsnorm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, accumulate=True)
