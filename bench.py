@@ -31,7 +31,8 @@ def train_flops_per_token(cfg, S):
     (causal attention counted at half the square, tied head counted once as a GEMM, embedding gather excluded)."""
     d, I, H, Dh, KVH, L, V = (cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.head_dim,
                               cfg.num_key_value_heads, cfg.num_hidden_layers, cfg.vocab_size)
-    blocks = L * (d * (H + 2 * KVH) * Dh + H * Dh * d + 3 * d * I)
+    mlp = 2 if getattr(cfg, "arch", "llama") == "gpt2" else 3      # c_fc + c_proj, or gate + up + down
+    blocks = L * (d * (H + 2 * KVH) * Dh + H * Dh * d + mlp * d * I)
     fwd = 2 * (blocks + d * V) + L * 2 * S * (H * Dh)
     return 3 * fwd
 
@@ -111,12 +112,16 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--model", choices=["default", "aria"], default="default",
+    ap.add_argument("--model", choices=["default", "aria", "gpt2"], default="default",
                     help="aria: the ~650M Llama-architecture stand-in of the other benchmark configurations "
-                         "(e.g. --batch 8 --seq 4096, --batch 1 --seq 16384); decode and CPU legs are skipped")
+                         "(e.g. --batch 8 --seq 4096, --batch 1 --seq 16384); gpt2: the GPT-2 variant with its "
+                         "dropout of 0.1 (--pdrop); decode and CPU legs are skipped for both")
+    ap.add_argument("--pdrop", type=float, default=0.1, help="dropout probability of --model gpt2")
     args = ap.parse_args()
 
     from mgen import MidiLM, default_decoder, aria_style_llama, ops
+    from mgen.config import gpt2_decoder
+    from mgen.gpt2 import MidiGPT2LM
     from mgen.trainer import Trainer, init_distributed_from_env
 
     if os.environ.get("MGEN_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack after that many seconds
@@ -132,10 +137,15 @@ def main():
         cfg.max_position_embeddings = max(cfg.max_position_embeddings, S)
         args.decode_tokens, args.no_cpu_baseline = 0, True
         wl = "Aria-style Llama stand-in (L16 d1536 H24xDh64 I6144 V17727 untied)"
+    elif args.model == "gpt2":
+        cfg = gpt2_decoder(pdrop=args.pdrop)
+        cfg.max_position_embeddings = max(cfg.max_position_embeddings, S)
+        args.decode_tokens, args.no_cpu_baseline = 0, True
+        wl = f"GPT-2 variant (L6 d512 H8xDh64 I2048 V30000 tied, dropout {args.pdrop})"
     else:
         cfg = default_decoder()
         wl = "default decoder (MidiQwen shape: L14 d512 H8xDh128 I2048 V151936 tied)"
-    model = MidiLM(cfg, device=dev, seed=0)
+    model = (MidiGPT2LM if args.model == "gpt2" else MidiLM)(cfg, device=dev, seed=0)
     trainer = Trainer(model, lr=5e-5, num_epochs=12, steps_per_epoch=1000, warmup=1000, max_grad_norm=1.0)
     g = torch.Generator().manual_seed(1234 + rank)
     ids = torch.randint(3, min(30000, cfg.vocab_size), (B, S), generator=g).to(dev)
