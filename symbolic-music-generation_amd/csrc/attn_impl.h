@@ -44,6 +44,7 @@ struct AttnArgs {
     int B, S, H, KVH;
     float scale;
     int gx, gy, gz;  // logical grid: row blocks, head (pair) index, batch; launched as one dimension
+    int nqb;         // forward: query blocks per sequence (a workgroup takes two of them, gx = ceil(nqb / 2))
     // dropout on the attention probabilities (kernels instantiated with DROP): element (b*H + h, q, key) is kept iff
     // drop_fmix32(drop_rowkey(drop_key, b*H + h, q) ^ key) >= drop_thresh; kept probabilities count 1 / (1 - p)
     unsigned long long drop_key;
@@ -148,140 +149,517 @@ __device__ __forceinline__ void store_rows_T(const f32x16 (&acc)[DB], bf16* __re
 }
 
 // ===================================================================================================
-// forward
+// Tile streaming shared by the three kernels.
+//
+// A streamed operand (K, V in forward / dQ; Q, dO in dK/dV) is read through a buffer descriptor that covers the
+// rows of ONE batch element from the first head of the tile row on: row r, 16-byte chunk c sits at byte offset
+// r * stride_bytes + 16 c. Every lane keeps the offsets of its pieces of a 64-row tile in registers (computed once),
+// the tile's first row enters as the scalar offset of the load, and rows at or past the sequence end are outside
+// the descriptor's range and arrive as zeros: issuing a tile costs no vector arithmetic.
 // ===================================================================================================
+template <int NW>   // waves per workgroup sharing the tile: each issues 16 / NW one-KiB pieces (4 rows each)
+struct TileStream {
+    static constexpr int NP = 16 / NW;
+    u32x4 rsrc;      // buffer descriptor (scalar registers)
+    int voff;        // this lane's offset in the wave's first piece; the wave's pieces lie 4 NW rows apart, a multiple
+                     // of 16 rows for NW >= 4, which leaves the chunk swizzle unchanged: they differ by a scalar
+    int row_bytes;   // token stride in bytes
+
+    // base, tok_stride and S must be the same in every lane (kernel arguments and workgroup / wave indices)
+    __device__ __forceinline__ void init(const bf16* base, long tok_stride, int S, int wave, int lane) {
+        static_assert(NW == 4 || NW == 8, "pieces of one wave must be a multiple of 16 rows apart");
+        row_bytes = (int)(tok_stride * 2);
+        const unsigned long long p = (unsigned long long)base;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+        rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xFFFFu);   // stride 0: raw buffer
+        rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)((S - 1) * row_bytes + ROWB));
+        rsrc[3] = 0x00020000u;
+        const int row = wave * 4 + (lane >> 4);
+        voff = row * row_bytes + 16 * ((lane & 15) ^ swz256(row));
+    }
+    // Piece j (0 .. NP-1) of this wave of rows [row0, row0 + 64) into the 16 KiB image at LDS byte address lds_base
+    // (scalar); wave = this wave's (scalar) index. An asm statement: the compiler does not know that an LDS write is
+    // pending (it would drain it with s_waitcnt vmcnt(0) in front of the next transposed LDS read, in the middle of
+    // the tile the prefetch is meant to overlap). The caller waits (asm s_waitcnt vmcnt) and passes a barrier before
+    // anyone reads the image. M0 (the instruction's LDS base) is saved and restored.
+    __device__ __forceinline__ void issue_piece(int j, int row0, unsigned lds_base, int wave) const {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave + NW * j) * 1024u);
+        const int soff = __builtin_amdgcn_readfirstlane((row0 + 4 * NW * j) * row_bytes);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    }
+    __device__ __forceinline__ void issue(int row0, unsigned lds_base, int wave) const {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) issue_piece(j, row0, lds_base, wave);
+    }
+};
+
+// per-lane byte offsets inside an IMG256 tile of the two kinds of operand read; rows and columns that are
+// multiples of 16 rows / one whole tile enter as immediates of the DS instruction (+4096 per 16 rows)
+// row read, k-step ks (absolute, 0..7), lane's row r = lane & 31 (+32 rows = +8192)
+__device__ __forceinline__ int row_frag_off(int ks, int lane) {
+    const int r = lane & 31;
+    return 256 * r + 16 * ((2 * ks + (lane >> 5)) ^ swz256(r));
+}
+// transposed read in accumulator order (frag_col_img256<true>), 32-column block cb (absolute, 0..3), second = the
+// read that supplies elements 4..7
+__device__ __forceinline__ int col_frag_off(int cb, bool second, int lane) {
+    const int g = lane >> 4, i = lane & 15, h = g >> 1, q = i >> 2, p = i & 3;
+    const int row = 4 * h + q + (second ? 8 : 0);
+    const int ch = 4 * cb + 2 * (g & 1) + (p >> 1);
+    return 256 * row + 16 * (ch ^ swz256(row)) + 8 * (p & 1);
+}
+__device__ __forceinline__ bf16x8 col_frag(const char* smem, int off_a, int off_b) {
+    s16x4 lo = lds_read_tr16(smem, off_a);
+    s16x4 hi = lds_read_tr16(smem, off_b);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+// the other half-wave's value of a per-row quantity (lanes l and l ^ 32 hold the two halves of a row)
+__device__ __forceinline__ float other_half(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned lo = r[0], hi = r[1];   // (named: a bit cast applied to a vector element reads element 0)
+    const unsigned other = (threadIdx.x & 32) ? lo : hi;
+    return __builtin_bit_cast(float, other);
+}
+
+// ===================================================================================================
+// forward
+//
+// One wave per SIMD with the whole register file: a workgroup is 4 waves, a wave owns 64 query rows (two 32-row
+// blocks A and B that share every K and V fragment it reads from LDS), so a workgroup covers 256 rows of one head
+// (head_dim 128) or 128 rows of a pair of heads (head_dim 64). The output accumulators (O^T, 128 registers) and the
+// query fragments live in the accumulator half of the register file; scores, probabilities and addresses in the
+// vector half.
+//
+// The tile loop is software pipelined so that the matrix pipe always has work that does not depend on the vector
+// ALU's current work:
+//     phase X(j):  S(j+1) = K(j+1) Q^T   (MFMA)   beside   p = exp2(S(j) - m)  (first part, VALU)
+//     phase Y(j):  O     += V(j) P(j)    (MFMA)   beside   rest of the exponentials, then rowmax(S(j+1))
+// Each MFMA is followed by its share of the vector work and the LDS reads of a later MFMA, and a scheduling fence
+// keeps that placement. The MFMAs are asm statements so that their register classes are fixed: scores land in
+// vector registers (no copies out of the accumulator file), O stays in accumulator registers for the whole kernel.
+// Nothing inside an asm string is padded by the compiler: operands written by the vector ALU are produced at least
+// one MFMA slot before the MFMA that reads them, MFMA results are read by vector code a phase later or behind an
+// explicit s_nop.
+//
+// K and V tiles travel through two-slot rings in LDS with one workgroup barrier per tile: after the barrier of
+// iteration j, K(j+1) and V(j) are complete and K(j+2), V(j+1) are issued into the slots whose last readers
+// (phase X(j-1), phase Y(j-1)) are behind that barrier.
+//
+// The running maximum of a row is raised only when a tile's maximum exceeds it by more than 2^RESCALE_LOG2 in the
+// exponent's units: until then the probabilities are taken against the older reference (they stay below
+// 2^RESCALE_LOG2: exact in fp32, bf16 keeps its relative precision), and the accumulators are not rescaled.
+// ===================================================================================================
+constexpr float RESCALE_LOG2 = 6.0f;
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// Accumulator registers are addressed by NUMBER in these statements, so a tile of O or a query fragment stays where
+// it is for the whole kernel and no statement carries a 16-register tied operand through the loop. The compiler does
+// not know about it: the kernels keep to a64 and above, the source is compiled with vector-register spills to
+// accumulator registers switched off, and the build audits the assembly (no compiler-generated v_accvgpr_* at or
+// above a64, no scratch).
+template <int ACC>   // a[ACC : ACC+15] += A(v) * B(v)
+__device__ __forceinline__ void mfma_acc(const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" : : "v"(a), "v"(b), "i"(ACC), "i"(ACC + 15));
+}
+template <int QA>    // d(v) += A(v) * B(a[QA : QA+3])
+__device__ __forceinline__ void mfma_vq(f32x16& d, const bf16x8& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(QA), "i"(QA + 3));
+}
+template <int QA>    // d(v) = A(v) * B(a[QA : QA+3])
+__device__ __forceinline__ void mfma_vq0(f32x16& d, const bf16x8& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(QA), "i"(QA + 3));
+}
+template <int A> __device__ __forceinline__ void acc_write(float x) {
+    asm volatile("v_accvgpr_write_b32 a%c1, %0" : : "v"(x), "i"(A));
+}
+template <int A> __device__ __forceinline__ float acc_read() {
+    float x; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "i"(A)); return x;
+}
+template <int A> __device__ __forceinline__ void acc_scale(float f) {
+    float t; asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c2, %0"
+                          : "=&v"(t) : "v"(f), "i"(A));
+}
+// Vector ALU steps of the pipelined loops as asm statements: their place between the MFMAs is part of the design,
+// and asm statements are neither reordered nor merged into packed forms. A transcendental's result is read no
+// earlier than two statements later (one wait state is required).
+__device__ __forceinline__ float a_fma(float x, float y, float z) {
+    float d; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d;
+}
+__device__ __forceinline__ float a_exp2(float x) { float d; asm volatile("v_exp_f32 %0, %1" : "=v"(d) : "v"(x)); return d; }
+__device__ __forceinline__ float a_add(float x, float y) {
+    float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d;
+}
+__device__ __forceinline__ float a_max3(float x, float y, float z) {
+    float d; asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d;
+}
+__device__ __forceinline__ unsigned a_cvt_pk_bf16(float lo, float hi) {
+    unsigned d; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi)); return d;
+}
+
 template <int HD, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(AttnArgs a) {
     using G = Geo<HD>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][K tile | V tile]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int KS = G::KS, DB = G::DB;
+    constexpr int QROWS = HD == 128 ? 256 : 128;     // query rows of one head per workgroup
+    constexpr int GX = 4 * KS, GY = 8 * DB;          // MFMAs of phase X and of phase Y
+    constexpr int KRING = 0, VRING = 2 * TILE;       // LDS: K slots at 0 / 16 KiB, V slots at 32 / 48 KiB
+    constexpr int QREG = 4 * TILE;                   // the workgroup's query rows: QROWS / 64 tiles
+    constexpr int STG = QREG + (QROWS / 64) * TILE;  // output staging: 8 KiB per wave
+    // accumulator registers, addressed by number: O[blk][db] tiles, then Q[blk][ks]. The range starts at a64: when
+    // the compiler runs out of vector registers it may place values of its own in accumulator registers, lowest
+    // numbers first (the build's audit, tools/audit_attn_asm.py, fails if it ever reaches a64)
+    constexpr int OACC = 64, QACC = 192;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    asm volatile("" ::: "a255");                     // makes the kernel allocate all 256 accumulator registers
+#ifdef MGEN_ATTN_STAMPS   // diagnostic build: cycle stamps of the kernel's sections, written over part of LSE
+    unsigned long long st0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st1 = 0, st2 = 0, st3 = 0;
+#define STAMP(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(x)
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Coords bid = block_coords(a);
-    const int qb = a.gx - 1 - bid.x;  // heaviest (latest) query blocks first
+    // A workgroup handles the query blocks nqb - 1 - x and x one after the other (the heavy one first): every
+    // workgroup then streams the same number of tiles, so the chip's workgroup slots (one per CU: the kernel uses the
+    // whole register file) free up together and the in-order dispatcher never waits on one busy XCD.
+    const int qb_hi = a.nqb - 1 - bid.x, qb_lo = bid.x;
+    const int npass = qb_lo < qb_hi ? 2 : 1;
     const int b = bid.z;
     const int sub = HD == 128 ? 0 : (wave >> 1);             // which head of the pair (head_dim 64)
-    const int wq = HD == 128 ? wave : (wave & 1);            // which 32-query slice of the block
+    const int wq = HD == 128 ? wave : (wave & 1);            // which 64-query slice of the block
     const int h = HD == 128 ? bid.y : 2 * bid.y + sub;
     const int kv_first = HD == 128 ? h / (a.H / a.KVH) : 2 * bid.y;  // first kv head of the tile row
     const int ks0 = 4 * sub, db0 = 2 * sub;                  // this head's k-steps / d-blocks inside the tile row
     const int S = a.S;
     const long tok0 = (long)b * S;
-    const int q0 = qb * G::ROWS, qw0 = q0 + wq * 32;
-    const bf16* Kb = a.K + (long)kv_first * HD;
-    const bf16* Vb = a.V + (long)kv_first * HD;
+    int q0, qw0, J, jl, my_q;   // of the current pass
+    auto set_block = [&](int qb) {
+        q0 = qb * QROWS;
+        qw0 = q0 + wq * 64;
+        J = min(q0 + QROWS - 1, S - 1) / 64 + 1;      // tiles the workgroup streams
+        jl = qw0 < S ? qw0 / 64 : -1;                 // this wave's last tile, the one on its diagonal
+        my_q = qw0 + (lane & 31);                     // block A's row of this lane; block B's is my_q + 32
+    };
 
-    bf16x8 qf[G::KS];
-    load_own_rows<G::KS>(qf, a.Q + (long)h * HD, a.sq, tok0, qw0, S, lane);
-
-    f32x16 o[G::DB];
+    TileStream<4> Ks, Vs, Qs;
+    Ks.init(a.K + tok0 * a.sk + (long)kv_first * HD, a.sk, S, wave, lane);
+    Vs.init(a.V + tok0 * a.sv + (long)kv_first * HD, a.sv, S, wave, lane);
+    Qs.init(a.Q + tok0 * a.sq + (long)(HD == 128 ? h : 2 * bid.y) * HD, a.sq, S, wave, lane);
+    const unsigned lds0 = lds_addr(smem);
+    auto issue_first = [&]() {   // what a pass needs before its tile loop: its query rows, K(0), K(1), V(0)
+        Ks.issue(0, lds0 + KRING, wave);
 #pragma unroll
-    for (int db = 0; db < G::DB; ++db) zero16(o[db]);
-    float m = NEG_BIG, l = 0.f;
+        for (int t = 0; t < QROWS / 64; ++t) Qs.issue(q0 + 64 * t, lds0 + QREG + t * TILE, wave);
+        if (J > 1) Ks.issue(64, lds0 + KRING + TILE, wave);
+        Vs.issue(0, lds0 + VRING, wave);
+    };
+    set_block(qb_hi);
+    issue_first();
+
+    int koff[KS], voffa[DB], voffb[DB];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = row_frag_off(ks0 + ks, lane);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        voffa[db] = col_frag_off(db0 + db, false, lane);
+        voffb[db] = col_frag_off(db0 + db, true, lane);
+    }
+
+    float m[2], l[2], nm[2], mx[2];
     const float sl2 = a.scale * LOG2E;
-    const int my_q = qw0 + (lane & 31);
-    // key = kv0 + 32t + 4*(lane>>5) + c_r with c_r = (r&3) + 8*(r>>2): the register part occupies bits the rest leaves
-    // free, so the hash input is (rowkey ^ lane part) ^ c_r
-    unsigned rk = 0;
-    if constexpr (DROP) rk = drop_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)my_q) ^ (unsigned)(4 * (lane >> 5));
+    const int hh = lane >> 5;
+    unsigned rk[2] = {0u, 0u};   // dropout: element hash input is (rowkey ^ lane part) ^ c_r ^ tile part
 
-    const int last_key = min(q0 + G::ROWS - 1, S - 1);
-    const int ntiles = last_key / 64 + 1;
+    // ---- pieces of the pipeline -------------------------------------------------------------------
+    // row maximum of a score tile pair, one v_max3 per step n in [0, 32); on the diagonal tile the masked scores
+    // are overwritten first (key = 64 jl + 32 t + 4 hh + c_r against query = 64 jl + 32 blk + lane row)
+    auto max_step = [&](f32x16 (&sn)[2][2], auto nc, auto maskedc) {
+        constexpr int n = decltype(nc)::value;
+        constexpr bool MASKED = decltype(maskedc)::value;
+        constexpr int blk = n >> 4, t = (n >> 3) & 1, r = 2 * (n & 7);
+        if constexpr (MASKED) {
+            const int thr = 32 * blk + (lane & 31) - 32 * t - 4 * hh;   // masked when c_r > thr
+            // the empty asm pins these reads of MFMA results behind the asm statements before them: compiler-placed
+            // vector code could otherwise read the registers inside the MFMA's write latency
+            float v0 = sn[blk][t][r], v1 = sn[blk][t][r + 1];
+            asm volatile("" : "+v"(v0), "+v"(v1));
+            if ((r & 3) + 8 * (r >> 2) > thr) v0 = NEG_BIG;
+            if (((r + 1) & 3) + 8 * ((r + 1) >> 2) > thr) v1 = NEG_BIG;
+            sn[blk][t][r] = v0;
+            sn[blk][t][r + 1] = v1;
+            mx[blk] = a_max3(mx[blk], v0, v1);
+        } else {
+            mx[blk] = a_max3(mx[blk], sn[blk][t][r], sn[blk][t][r + 1]);
+        }
+    };
+    // Element e (0..63) of the exponential pipeline: probabilities in the order phase Y consumes them, fragment
+    // f = e / 8 = 2 (2 t + s2) + blk, register 8 s2 + e % 8 of S[blk][t]. Step n in [0, 67) runs the multiply-add of
+    // element n, the exponential of element n - 1, the row-sum add of element n - 2 and the bf16 packing of a
+    // finished pair.
+    unsigned pw[32];          // packed probabilities: fragment f = words 4 f .. 4 f + 3
+    float xs[64], ps[64];     // per-element temporaries (registers: every index is a compile-time constant)
+    float psum[2];
+    auto exp_step = [&](const f32x16 (&sc)[2][2], auto nc, int kv0) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (n < 64) xs[n] = a_fma(sc[(n >> 3) & 1][n >> 5][8 * ((n >> 4) & 1) + (n & 7)], sl2, nm[(n >> 3) & 1]);
+        if constexpr (n >= 1 && n < 65) ps[n - 1] = a_exp2(xs[n - 1]);
+        if constexpr (n >= 2 && n < 66) {
+            constexpr int e = n - 2, f = e >> 3;
+            psum[f & 1] = a_add(psum[f & 1], ps[e]);    // the normaliser counts every visible key, dropped or not
+            if constexpr (DROP) {
+                constexpr int k = f >> 1, r = 8 * (k & 1) + (e & 7);
+                const unsigned hsh = drop_fmix32(rk[f & 1] ^ (unsigned)(kv0 + 32 * (k >> 1)) ^ (unsigned)((r & 3) + 8 * (r >> 2)));
+                if (hsh < a.drop_thresh) ps[e] = 0.f;
+            }
+        }
+        if constexpr (n >= 3 && (n & 1)) pw[(n - 3) >> 1] = a_cvt_pk_bf16(ps[n - 3], ps[n - 2]);   // a finished pair
+    };
+    auto p_frag = [&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        const u32x4 w = {pw[4 * f], pw[4 * f + 1], pw[4 * f + 2], pw[4 * f + 3]};
+        return __builtin_bit_cast(bf16x8, w);
+    };
+    constexpr int NSTEP = 67;
+    constexpr int NX = 43;                   // exponential steps run beside phase X (fragments 0..4 complete)
+    constexpr int GE = HD == 128 ? 22 : 11;  // MFMA slots of phase Y that carry the remaining steps
 
-    tile_glds(Kb, a.sk, tok0, 0, S, smem, tid);
-    tile_glds(Vb, a.sv, tok0, 0, S, smem + TILE, tid);
+    // the rare path: raise the reference maxima, rescale the row sums and O
+    auto rescale = [&]() {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // O may just have been written by MFMAs
+        float alpha[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const float m_new = fmaxf(m[blk], mx[blk]);
+            alpha[blk] = fast_exp2((m[blk] - m_new) * sl2);
+            m[blk] = m_new;
+            l[blk] *= alpha[blk];
+        }
+        static_for<2 * DB * 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            acc_scale<OACC + i>(alpha[i / (16 * DB)]);
+        });
+    };
+    auto finish_max = [&]() {   // both halves of a row agree on its maximum; decide about the rescale
+        mx[0] = fmaxf(mx[0], other_half(mx[0]));
+        mx[1] = fmaxf(mx[1], other_half(mx[1]));
+        if (__any(fmaxf(mx[0] - m[0], mx[1] - m[1]) * sl2 > RESCALE_LOG2)) rescale();
+        nm[0] = -m[0] * sl2;
+        nm[1] = -m[1] * sl2;
+    };
+
+    // KIND 0: tiles j and j + 1 below the diagonal; 1: tile j + 1 is the diagonal tile; 2: tile j is the wave's last
+    auto iter = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], auto parc, auto kindc, int j) {
+        constexpr int PAR = decltype(parc)::value, KIND = decltype(kindc)::value;
+        constexpr int KB = KRING + (PAR ^ 1) * TILE;    // K(j+1)
+        constexpr int VB = VRING + PAR * TILE;          // V(j)
+        const int kv0 = 64 * j;
+        psum[0] = psum[1] = 0.f;
+        if constexpr (KIND != 2) {
+            // ---- phase X: 2 t x KS k-steps x 2 blocks; fragment u = t KS + ks serves both blocks
+            bf16x8 kf[2 * KS];
+            constexpr int AHEAD = 3;   // fragments read ahead of their MFMAs
+            static_for<AHEAD>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                kf[u] = lds_read_b128(smem, koff[u % KS] + KB + 8192 * (u / KS));
+            });
+            SCHED_FENCE();
+            static_for<GX>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, u = g >> 1, blk = g & 1, t = u / KS, ks = u % KS;
+                if constexpr (ks == 0) mfma_vq0<QACC + (blk * KS + ks) * 4>(sn[blk][t], kf[u]);
+                else mfma_vq<QACC + (blk * KS + ks) * 4>(sn[blk][t], kf[u]);
+                if constexpr (blk == 1 && u + AHEAD < 2 * KS)
+                    kf[u + AHEAD] = lds_read_b128(smem, koff[(u + AHEAD) % KS] + KB + 8192 * ((u + AHEAD) / KS));
+                static_for<(g + 1) * NX / GX - g * NX / GX>([&](auto ic) {
+                    exp_step(sc, std::integral_constant<int, g * NX / GX + decltype(ic)::value>{}, kv0);
+                });
+                SCHED_FENCE();
+            });
+        } else {
+            static_for<NX>([&](auto nc) { exp_step(sc, nc, kv0); });
+            SCHED_FENCE();
+        }
+        // ---- phase Y: 4 (t, s2) x DB d-blocks x 2 blocks; fragment u = (2 t + s2) DB + db serves both blocks
+        {
+            if constexpr (KIND != 2) mx[0] = mx[1] = NEG_BIG;
+            bf16x8 vf[4 * DB];
+            constexpr int AHEAD = 2;
+            auto vread = [&](auto uc) {
+                constexpr int u = decltype(uc)::value, k = u / DB, db = u % DB;
+                constexpr int im = VB + 8192 * (k >> 1) + 4096 * (k & 1);
+                vf[u] = col_frag(smem, voffa[db] + im, voffb[db] + im);
+            };
+            static_for<AHEAD>([&](auto uc) { vread(uc); });
+            SCHED_FENCE();
+            static_for<GY>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, u = g >> 1, blk = g & 1, k = u / DB, db = u % DB;
+                mfma_acc<OACC + (blk * DB + db) * 16>(vf[u], p_frag(std::integral_constant<int, 2 * k + blk>{}));
+                if constexpr (blk == 1 && u + AHEAD < 4 * DB) vread(std::integral_constant<int, u + AHEAD>{});
+                if constexpr (g < GE) {
+                    constexpr int lo = NX + g * (NSTEP - NX) / GE, hi = NX + (g + 1) * (NSTEP - NX) / GE;
+                    static_for<hi - lo>([&](auto ic) {
+                        exp_step(sc, std::integral_constant<int, lo + decltype(ic)::value>{}, kv0);
+                    });
+                }
+                if constexpr (KIND != 2) {
+                    constexpr int lo = g * 32 / GY, hi = (g + 1) * 32 / GY;
+                    static_for<hi - lo>([&](auto ic) {
+                        max_step(sn, std::integral_constant<int, lo + decltype(ic)::value>{},
+                                 std::integral_constant<bool, KIND == 1>{});
+                    });
+                }
+                SCHED_FENCE();
+            });
+        }
+        l[0] += psum[0];
+        l[1] += psum[1];
+        if constexpr (KIND != 2) finish_max();
+    };
+
+    f32x16 sa[2][2], sb[2][2];
+    for (int pass = 0; pass < npass; ++pass) {
+    // ---- prologue: O = 0, the query rows, scores and maxima of tile 0
+    static_for<2 * DB * 16>([&](auto ic) { acc_write<OACC + decltype(ic)::value>(0.f); });
+    m[0] = m[1] = NEG_BIG;
+    l[0] = l[1] = 0.f;
+    nm[0] = nm[1] = 0.f;
+    if constexpr (DROP) {
+        rk[0] = drop_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)my_q) ^ (unsigned)(4 * hh);
+        rk[1] = drop_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)(my_q + 32)) ^ (unsigned)(4 * hh);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    settle_frags<G::KS>(qf);
+    STAMP(st1);
+    {   // query rows -> accumulator registers (B operands of the score MFMAs): tile wq of the Q region, the image
+        // and the fragment reads are those of a K tile
+        bf16x8 qf[2][KS];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[blk][ks] = lds_read_b128(smem, koff[ks] + QREG + wq * TILE + 8192 * blk);
+        static_for<2 * KS * 4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const u32x4 w = __builtin_bit_cast(u32x4, qf[i / (4 * KS)][(i / 4) % KS]);
+            const unsigned word = w[i % 4];   // (named: a bit cast applied to a vector element reads element 0)
+            acc_write<QACC + i>(__builtin_bit_cast(float, word));
+        });
+    }
+    if (jl >= 0) {
+        static_for<2 * KS>([&](auto uc) {
+            constexpr int u = decltype(uc)::value, t = u / KS, ks = u % KS;
+            const bf16x8 kf = lds_read_b128(smem, koff[ks] + KRING + 8192 * t);
+            if constexpr (ks == 0) {
+                mfma_vq0<QACC + ks * 4>(sa[0][t], kf);
+                mfma_vq0<QACC + (KS + ks) * 4>(sa[1][t], kf);
+            } else {
+                mfma_vq<QACC + ks * 4>(sa[0][t], kf);
+                mfma_vq<QACC + (KS + ks) * 4>(sa[1][t], kf);
+            }
+        });
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        mx[0] = mx[1] = NEG_BIG;
+        if (jl == 0) static_for<32>([&](auto nc) { max_step(sa, nc, std::true_type{}); });
+        else static_for<32>([&](auto nc) { max_step(sa, nc, std::false_type{}); });
+        // the first maxima are the reference (O and the row sums are zero: nothing to rescale); every row sees key 0
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            m[blk] = fmaxf(mx[blk], other_half(mx[blk]));
+            nm[blk] = -m[blk] * sl2;
+        }
+    }
 
-    for (int j = 0; j < ntiles; ++j) {
-        const int cur = j & 1;
-        const int kv0 = j * 64;
-        if (j + 1 < ntiles) {  // next tile into the other buffer (last read one iteration ago, before a barrier)
-            char* nb = smem + (cur ^ 1) * 2 * TILE;
-            tile_glds(Kb, a.sk, tok0, kv0 + 64, S, nb, tid);
-            tile_glds(Vb, a.sv, tok0, kv0 + 64, S, nb + TILE, tid);
-        }
-        const char* Kt = smem + cur * 2 * TILE;
-        const char* Vt = Kt + TILE;
-        if (kv0 <= qw0 + 31) {  // wave-uniform: this wave has at least one visible key in the tile
-            // MASKED is a compile-time flag: only tiles that straddle the diagonal pay for the key > query test
-            auto tile = [&](auto masked) {
-                constexpr bool MASKED = decltype(masked)::value;
-                f32x16 s[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    zero16(s[t]);
-#pragma unroll
-                    for (int ks = 0; ks < G::KS; ++ks)
-                        s[t] = mfma32(frag_row_img256(Kt, 32 * t, ks0 + ks, lane), qf[ks], s[t]);
-                }
-                // running max in the RAW score domain (the scale is positive); the scale is folded into the
-                // exponent's fma below
-                float mx = NEG_BIG;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (MASKED) {
-                            const int key = kv0 + 32 * t + acc_row(r, lane);
-                            if (key > my_q) s[t][r] = NEG_BIG;
-                        }
-                        mx = fmaxf(mx, s[t][r]);
-                    }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                if (__any(mx > m)) {  // wave-uniform; when no row's max grew the rescale factor is exactly 1
-                    const float m_new = fmaxf(m, mx);
-                    const float alpha = fast_exp2((m - m_new) * sl2);
-                    m = m_new;
-                    l *= alpha;
-#pragma unroll
-                    for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-                }
-                const float nm = -m * sl2;
-                float psum = 0.f;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float p = fast_exp2(__builtin_fmaf(s[t][r], sl2, nm));
-                        psum += p;   // the softmax normaliser counts every visible key, dropped or not
-                        if constexpr (DROP) {
-                            const unsigned hsh = drop_fmix32(rk ^ (unsigned)(kv0 + 32 * t) ^ (unsigned)((r & 3) + 8 * (r >> 2)));
-                            if (hsh < a.drop_thresh) p = 0.f;
-                        }
-                        s[t][r] = p;
-                    }
-                l += psum;
-                bf16x8 pf[2][2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    pf[t][0] = acc_to_frag<0>(s[t]);
-                    pf[t][1] = acc_to_frag<1>(s[t]);
-                }
-                // O^T[d][q] += V^T[d][key] * P^T[key][q]
-#pragma unroll
-                for (int db = 0; db < G::DB; ++db)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int s2 = 0; s2 < 2; ++s2)
-                            o[db] = mfma32(frag_col_img256<true>(Vt, 32 * t + 16 * s2, 32 * (db0 + db), lane),
-                                           pf[t][s2], o[db]);
-            };
-            if (kv0 + 63 > qw0) tile(std::true_type{});
-            else tile(std::false_type{});
-        }
+    auto body = [&](f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], auto parc, int j) {
+        constexpr int PAR = decltype(parc)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __syncthreads();   // K(j+1), V(j) complete; every wave is past its reads of K(j), V(j-1)
+        if (j + 2 < J) Ks.issue(64 * (j + 2), lds0 + KRING + PAR * TILE, wave);
+        if (j + 1 < J) Vs.issue(64 * (j + 1), lds0 + VRING + (PAR ^ 1) * TILE, wave);
+        if (j + 1 < jl) iter(sc, sn, parc, std::integral_constant<int, 0>{}, j);
+        else if (j + 1 == jl) iter(sc, sn, parc, std::integral_constant<int, 1>{}, j);
+        else if (j == jl) iter(sc, sn, parc, std::integral_constant<int, 2>{}, j);
+    };
+    STAMP(st2);
+    for (int j = 0; j < J; j += 2) {
+        body(sa, sb, std::integral_constant<int, 0>{}, j);
+        if (j + 1 < J) body(sb, sa, std::integral_constant<int, 1>{}, j + 1);
     }
+    STAMP(st3);
 
-    const float lt = l + __shfl_xor(l, 32, 64);
-    if (my_q < S) {
-        const float inv = (DROP ? a.drop_inv_keep : 1.f) / lt;
-        store_rows_T<G::DB>(o, a.Out + (tok0 + my_q) * a.so + (long)h * HD, inv, lane);
-        if (lane < 32 && a.LSE) a.LSE[((long)b * a.H + h) * S + my_q] = (m * sl2 + __log2f(lt)) * LN2;
+    // ---- epilogue. The next pass's first tiles are requested first (they travel while this pass's rows are written
+    // out); O^T goes through LDS (8 KiB of this wave's own, one 32-row block at a time) and leaves as whole rows.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // every wave is past its last K and V reads
+    const int qw0_out = qw0;
+    float lt[2], mm[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        lt[blk] = l[blk] + other_half(l[blk]);
+        mm[blk] = m[blk];
     }
+    if (pass + 1 < npass) {
+        set_block(qb_lo);
+        issue_first();
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    char* obuf = smem + STG + wave * 8192;
+    static_for<2>([&](auto bc) {
+        constexpr int blk = decltype(bc)::value;
+        const float inv = (DROP ? a.drop_inv_keep : 1.f) / lt[blk];
+        static_for<DB * 4>([&](auto ic) {   // O^T[d = 32 db + 8 g4 + 4 hh + e][q] -> row = lane row, columns d
+            constexpr int db = decltype(ic)::value / 4, g4 = decltype(ic)::value % 4;
+            bf16x4 ov;
+            static_for<4>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                ov[e] = (bf16)(acc_read<OACC + (blk * DB + db) * 16 + 4 * g4 + e>() * inv);
+            });
+            *reinterpret_cast<bf16x4*>(obuf + img256_off(lane & 31, 4 * (db0 + db) + g4) + 8 * hh) = ov;
+        });
+        const int q = qw0_out + 32 * blk + (lane & 31);
+        if (q < S && lane < 32 && a.LSE) a.LSE[((long)b * a.H + h) * S + q] = (mm[blk] * sl2 + __log2f(lt[blk])) * LN2;
+        // (a wave reads back only what it wrote; with head_dim 64 a row holds its head in its half of the chunks)
+        constexpr int CPR = HD / 8;                  // 16-byte chunks per output row
+        constexpr int RPI = 64 / CPR;                // rows per store instruction
+        const int c = lane % CPR, r0 = lane / CPR;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int row = i * RPI + r0, qr = qw0_out + 32 * blk + row;
+            const bf16x8 v = lds_read_b128(obuf, img256_off(row, 4 * db0 + c));
+            if (qr < S) *reinterpret_cast<bf16x8*>(a.Out + (tok0 + qr) * a.so + (long)h * HD + 8 * c) = v;
+        }
+    });
+#ifdef MGEN_ATTN_STAMPS
+    {
+        const unsigned long long st4 = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {   // per wave (raw 32-bit words): start, wait for the first tiles, prologue, loop, epilogue, J, jl, ids
+            unsigned* d = reinterpret_cast<unsigned*>(a.LSE + ((long)b * a.H + h) * S + qw0_out);
+            d[0] = (unsigned)st0; d[1] = (unsigned)(st1 - st0); d[2] = (unsigned)(st2 - st1); d[3] = (unsigned)(st3 - st2);
+            d[4] = (unsigned)(st4 - st3); d[5] = (unsigned)pass; d[6] = (unsigned)npass;
+            d[7] = __builtin_amdgcn_s_getreg((15 << 11) | 4);     // HW_ID bits 0..15: wave, simd, pipe, cu, sh, se
+            d[8] = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // XCC_ID
+            d[9] = (unsigned)(st0 >> 32);
+        }
+        st0 = st4;
+    }
+#endif
+    }   // pass
+#undef STAMP
 }
 
 // ===================================================================================================
@@ -623,15 +1001,27 @@ int attn_fwd_impl(const void* q, const void* k, const void* v, void* out, float*
     a.sq = sq; a.sk = sk; a.sv = sv; a.so = so; a.B = B; a.S = S; a.H = H; a.KVH = KVH; a.scale = scale;
     if (int e = check_common(a, head_dim, who)) return e;
     if (int e = set_drop(a, p, key, who)) return e;
-    MGEN_REQUIRE(so % 4 == 0, "%s: output token stride must be a multiple of 4", who);
     const dim3 block(256);
-    a.gx = head_dim == 128 ? (S + 127) / 128 : (S + 63) / 64;
+    a.nqb = head_dim == 128 ? (S + 255) / 256 : (S + 127) / 128;
+    a.gx = (a.nqb + 1) / 2;
     a.gy = head_dim == 128 ? H : H / 2;
     a.gz = B;
     MGEN_REQUIRE((long)a.gx * a.gy * a.gz < (1L << 31), "%s: grid too large", who);
+    MGEN_REQUIRE((long)S * sk < (1L << 30) && (long)S * sv < (1L << 30), "%s: one sequence's K or V exceeds 2 GiB", who);
     const dim3 grid((unsigned)(a.gx * a.gy * a.gz));
-    if (head_dim == 128) hipLaunchKernelGGL((attn_fwd_kernel<128, kDrop>), grid, block, 4 * TILE, stream, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<64, kDrop>), grid, block, 4 * TILE, stream, a);
+    MGEN_REQUIRE(so % 8 == 0, "%s: output token stride must be a multiple of 8", who);
+    MGEN_REQUIRE((long)S * sq < (1L << 30), "%s: one sequence's Q exceeds 2 GiB", who);
+    // more than the default 64 KiB of dynamic LDS has to be asked for, once per kernel and device
+    static bool asked_fwd[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!asked_fwd[dev]) {
+        if (int e = set_lds(attn_fwd_kernel<128, kDrop>, 10 * TILE, who)) return e;
+        if (int e = set_lds(attn_fwd_kernel<64, kDrop>, 8 * TILE, who)) return e;
+        asked_fwd[dev] = true;
+    }
+    if (head_dim == 128) hipLaunchKernelGGL((attn_fwd_kernel<128, kDrop>), grid, block, 10 * TILE, stream, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<64, kDrop>), grid, block, 8 * TILE, stream, a);
     return mgen_check_launch(who);
 }
 

@@ -183,6 +183,11 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// LDS byte address (what M0 and the DS instructions take) of a pointer into the workgroup's LDS
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(__UINTPTR_TYPE__)(const __attribute__((address_space(3))) char*)p;
+}
+
 // Bijective remap of a 1-D block id so that the blocks that share an XCD (ids congruent mod 8 under round-robin
 // dispatch) receive one contiguous range of work items. Speed only; any placement is correct.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
