@@ -166,13 +166,15 @@ struct TileStream {
     int row_bytes;   // token stride in bytes
 
     // base, tok_stride and S must be the same in every lane (kernel arguments and workgroup / wave indices)
-    __device__ __forceinline__ void init(const bf16* base, long tok_stride, int S, int wave, int lane) {
+    // span_bytes = bytes of a token row, from base on, that the stream may touch (one tile row, or several heads)
+    __device__ __forceinline__ void init(const bf16* base, long tok_stride, int S, int wave, int lane,
+                                         int span_bytes = ROWB) {
         static_assert(NW == 4 || NW == 8, "pieces of one wave must be a multiple of 16 rows apart");
         row_bytes = (int)(tok_stride * 2);
         const unsigned long long p = (unsigned long long)base;
         rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
         rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xFFFFu);   // stride 0: raw buffer
-        rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)((S - 1) * row_bytes + ROWB));
+        rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)((S - 1) * row_bytes + span_bytes));
         rsrc[3] = 0x00020000u;
         const int row = wave * 4 + (lane >> 4);
         voff = row * row_bytes + 16 * ((lane & 15) ^ swz256(row));
@@ -182,17 +184,18 @@ struct TileStream {
     // pending (it would drain it with s_waitcnt vmcnt(0) in front of the next transposed LDS read, in the middle of
     // the tile the prefetch is meant to overlap). The caller waits (asm s_waitcnt vmcnt) and passes a barrier before
     // anyone reads the image. M0 (the instruction's LDS base) is saved and restored.
-    __device__ __forceinline__ void issue_piece(int j, int row0, unsigned lds_base, int wave) const {
+    // extra = a byte offset inside the token row (another head of the row the descriptor starts at)
+    __device__ __forceinline__ void issue_piece(int j, int row0, unsigned lds_base, int wave, int extra = 0) const {
         unsigned keep;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave + NW * j) * 1024u);
-        const int soff = __builtin_amdgcn_readfirstlane((row0 + 4 * NW * j) * row_bytes);
+        const int soff = __builtin_amdgcn_readfirstlane((row0 + 4 * NW * j) * row_bytes + extra);
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
                      "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
     }
-    __device__ __forceinline__ void issue(int row0, unsigned lds_base, int wave) const {
+    __device__ __forceinline__ void issue(int row0, unsigned lds_base, int wave, int extra = 0) const {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) issue_piece(j, row0, lds_base, wave);
+        for (int j = 0; j < NP; ++j) issue_piece(j, row0, lds_base, wave, extra);
     }
 };
 
@@ -696,9 +699,12 @@ template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Coords bid = block_coords(a);
-    const int qb = a.gx - 1 - bid.x;
+    // two query blocks per workgroup, nqb - 1 - x (heavy) then x (light): every workgroup streams the same number
+    // of tiles (see the forward kernel)
+    const int npass = bid.x < a.nqb - 1 - bid.x ? 2 : 1;
     const int b = bid.z;
     const int sub = HD == 128 ? 0 : (wave >> 1);
     const int wq = HD == 128 ? wave : (wave & 1);
@@ -707,9 +713,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int ks0 = 4 * sub, db0 = 2 * sub;
     const int S = a.S;
     const long tok0 = (long)b * S;
+    TileStream<4> Ks, Vs;
+    Ks.init(a.K + tok0 * a.sk + (long)kv_first * HD, a.sk, S, wave, lane);
+    Vs.init(a.V + tok0 * a.sv + (long)kv_first * HD, a.sv, S, wave, lane);
+    const unsigned lds0 = lds_addr(smem);
+    const float sl2 = a.scale * LOG2E;
+    for (int pass = 0; pass < npass; ++pass) {
+    const int qb = pass == 0 ? a.nqb - 1 - bid.x : bid.x;
     const int q0 = qb * G::ROWS, qw0 = q0 + wq * 32;
-    const bf16* Kb = a.K + (long)kv_first * HD;
-    const bf16* Vb = a.V + (long)kv_first * HD;
+    Ks.issue(0, lds0, wave);
+    Vs.issue(0, lds0 + TILE, wave);
 
     bf16x8 qf[G::KS], dof[G::KS];
     load_own_rows<G::KS>(qf, a.Q + (long)h * HD, a.sq, tok0, qw0, S, lane);
@@ -718,7 +731,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int cq = min(my_q, S - 1);
     const float lse2 = a.LSE[((long)b * a.H + h) * S + cq] * LOG2E;
     const float delta = a.Delta[((long)b * a.H + h) * S + cq];
-    const float sl2 = a.scale * LOG2E;
     unsigned rk = 0;   // as in the forward kernel
     if constexpr (DROP) rk = drop_rowkey(a.drop_key, (unsigned)(b * a.H + h), (unsigned)my_q) ^ (unsigned)(4 * (lane >> 5));
 
@@ -729,8 +741,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
     const int last_key = min(q0 + G::ROWS - 1, S - 1);
     const int ntiles = last_key / 64 + 1;
 
-    tile_glds(Kb, a.sk, tok0, 0, S, smem, tid);
-    tile_glds(Vb, a.sv, tok0, 0, S, smem + TILE, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     settle_frags<G::KS>(qf);
@@ -740,9 +750,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         const int cur = j & 1;
         const int kv0 = j * 64;
         if (j + 1 < ntiles) {
-            char* nb = smem + (cur ^ 1) * 2 * TILE;
-            tile_glds(Kb, a.sk, tok0, kv0 + 64, S, nb, tid);
-            tile_glds(Vb, a.sv, tok0, kv0 + 64, S, nb + TILE, tid);
+            const unsigned nb = lds0 + (cur ^ 1) * 2 * TILE;
+            Ks.issue(kv0 + 64, nb, wave);
+            Vs.issue(kv0 + 64, nb + TILE, wave);
         }
         const char* Kt = smem + cur * 2 * TILE;
         const char* Vt = Kt + TILE;
@@ -787,6 +797,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs a) {
         __syncthreads();
     }
     if (my_q < S) store_rows_T<G::DB>(dq, a.dQ + (tok0 + my_q) * a.sdq + (long)h * HD, a.scale, lane);
+    }   // pass (the last tile loop iteration ended with a barrier: both LDS buffers are free again)
 }
 
 // ===================================================================================================
@@ -801,19 +812,31 @@ template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     using G = Geo<HD>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Coords bid = block_coords(a);
-    const int kb = bid.x, b = bid.z;
+    // two key blocks per workgroup, x (heavy: every query tile from its first key on) then nqb - 1 - x (light):
+    // every workgroup streams the same number of tiles (see the forward kernel)
+    const int npass = bid.x < a.nqb - 1 - bid.x ? 2 : 1;
+    const int b = bid.z;
     const int sub = HD == 128 ? 0 : (wave >> 1);
     const int wk = HD == 128 ? wave : (wave & 1);
     const int kvh = HD == 128 ? bid.y : 2 * bid.y + sub;
     const int ks0 = 4 * sub, db0 = 2 * sub;
     const int S = a.S;
     const long tok0 = (long)b * S;
-    const int k0 = kb * G::ROWS, kw0 = k0 + wk * 32;
-    const int my_k = kw0 + (lane & 31);
     const int group = HD == 128 ? a.H / a.KVH : 1;  // head_dim 64 requires H == KVH
     const float sl2 = a.scale * LOG2E;
+    // Q and dO tiles of every query head of the group through one descriptor each (the head enters as a byte offset)
+    const int hq_first = HD == 128 ? bid.y * group : 2 * bid.y;
+    TileStream<4> Qs, dOs;
+    Qs.init(a.Q + tok0 * a.sq + (long)hq_first * HD, a.sq, S, wave, lane, HD == 128 ? group * 256 : 256);
+    dOs.init(a.dO + tok0 * a.sdo + (long)hq_first * HD, a.sdo, S, wave, lane, HD == 128 ? group * 256 : 256);
+    const unsigned lds0 = lds_addr(smem);
+    for (int pass = 0; pass < npass; ++pass) {
+    const int kb = pass == 0 ? bid.x : a.nqb - 1 - bid.x;
+    const int k0 = kb * G::ROWS, kw0 = k0 + wk * 32;
+    const int my_k = kw0 + (lane & 31);
 
     bf16x8 kf[G::KS], vf[G::KS];
     load_own_rows<G::KS>(kf, a.K + (long)kvh * HD, a.sk, tok0, kw0, S, lane);
@@ -838,9 +861,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
         // first query head of the tile row for this step
         const int hq0 = HD == 128 ? bid.y * group + step / per_head : 2 * bid.y;
         const int qt0 = (t_first + step % per_head) * 64;
-        char* base = smem + buf * DKV_BUF;
-        tile_glds(a.Q + (long)hq0 * HD, a.sq, tok0, qt0, S, base, tid);
-        tile_glds(a.dO + (long)hq0 * HD, a.sdo, tok0, qt0, S, base + TILE, tid);
+        Qs.issue(qt0, lds0 + buf * DKV_BUF, wave, (hq0 - hq_first) * HD * 2);
+        dOs.issue(qt0, lds0 + buf * DKV_BUF + TILE, wave, (hq0 - hq_first) * HD * 2);
         if (tid < 64 * G::HPB) {
             const int q = min(qt0 + (tid & 63), S - 1);
             const long o = ((long)b * a.H + hq0 + (tid >> 6)) * S + q;
@@ -960,6 +982,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
         store_rows_T<G::DB>(dk, a.dK + (tok0 + my_k) * a.sdk + (long)kvh * HD, a.scale, lane);
         store_rows_T<G::DB>(dv, a.dV + (tok0 + my_k) * a.sdv + (long)kvh * HD, DROP ? a.drop_inv_keep : 1.f, lane);
     }
+    }   // pass (the last step ended with a barrier: both LDS buffers are free again)
 }
 
 int check_common(const AttnArgs& a, int head_dim, const char* who) {
@@ -1057,8 +1080,10 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* out, 
     const int nrb = head_dim == 128 ? (S + 127) / 128 : (S + 63) / 64;   // row blocks
     MGEN_REQUIRE((long)nrb * H * B < (1L << 31), "%s: grid too large", who);
     AttnArgs akv = a, aq = a;   // the two kernels walk different logical grids
-    akv.gx = nrb; akv.gy = head_dim == 128 ? KVH : KVH / 2; akv.gz = B;
-    aq.gx = nrb; aq.gy = head_dim == 128 ? H : H / 2; aq.gz = B;
+    akv.nqb = nrb; akv.gx = (nrb + 1) / 2; akv.gy = head_dim == 128 ? KVH : KVH / 2; akv.gz = B;
+    aq.nqb = nrb; aq.gx = (nrb + 1) / 2; aq.gy = head_dim == 128 ? H : H / 2; aq.gz = B;
+    MGEN_REQUIRE((long)S * sk < (1L << 30) && (long)S * sv < (1L << 30) && (long)S * sq < (1L << 30) &&
+                 (long)S * sdo < (1L << 30), "%s: one sequence's Q, K, V or dO exceeds 2 GiB", who);
     const dim3 gkv((unsigned)(akv.gx * akv.gy * akv.gz)), gq((unsigned)(aq.gx * aq.gy * aq.gz));
     // delta = rowsum(dO * O) holds with dropout too: sum_k P dP = sum_k P~ dP~ = dO . O
     if (head_dim == 128) {
