@@ -234,6 +234,12 @@ int mgen_collate_tokens(const long* flat, const long* offsets, const int* prompt
 /* 4-D position batches, MidiDataset4D._create_chunks (reference src/train_model_new.py:114-158): rows fp32 [total][4];
  * batch entry b takes chunk chunk_ids[b] of S rows, padded with [last start, 0, 2, 0]; labels = next row with the
  * start difference in column 0 (last label: the last row, difference 0), -100 on the padded tail. */
+/* The attention_mask of the forward call surface (reference src/model/model.py:142-143; the collator of
+ * src/train.py:33-35 pads on the right): sets bit 1 (value 2) of *err_flag if a row of mask [B][S] (int64) has a 0
+ * followed by a non-zero, i.e. is anything but right padding, the one form under which causal attention needs no
+ * mask for the real tokens. */
+int mgen_check_right_padding(const long* mask, int B, int S, int* err_flag, mgen_stream_t stream);
+
 int mgen_collate_pos4d(const float* rows, long total, const long* chunk_ids, float* pos, float* labels, long* mask,
                        long* ids, int B, int S, mgen_stream_t stream);
 
@@ -249,8 +255,10 @@ int mgen_cast(const void* in, void* out, long n, int kind, mgen_stream_t stream)
 
 /* ---- shifted cross entropy (ForCausalLMLoss, TF loss/loss_utils.py:49-71) -----------------------------------
  * labels int64 [B][S]; row (b,s) is scored against labels[b][s+1]. */
-int mgen_ce_count(const long* labels, long B, int S, long ignore_index, float* inv_count, int* count,
-                  mgen_stream_t stream);
+/* V > 0: labels outside [0, V) that are not ignore_index are left out of the count, as the loss kernels leave them
+ * out of the sum, and set bit 2 (value 4) of *err_flag (may be null): torch's cross_entropy asserts on them. */
+int mgen_ce_count(const long* labels, long B, int S, long ignore_index, float* inv_count, int* count, long V,
+                  int* err_flag, mgen_stream_t stream);
 /* rows `tok0 .. tok0+rows` of the flattened [B*S] token axis; logits [rows][ld] (bf16 or fp32) are replaced in place
  * by d(loss)/d(logits) when write_grad; row_loss[B*S] and lse_out[B*S] (may be null) are indexed by token. */
 int mgen_ce_fwd_bwd(void* logits, const long* labels, long tok0, long rows, int V, long ld, int S, long ignore_index,

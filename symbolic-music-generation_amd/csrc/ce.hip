@@ -45,7 +45,7 @@ template <> struct Row8<float> {
 // flight per thread.
 __global__ __launch_bounds__(1024) void ce_count_kernel(const long* __restrict__ labels, long B, int S,
                                                         long ignore_index, float* __restrict__ inv_count,
-                                                        int* __restrict__ count) {
+                                                        int* __restrict__ count, long V, int* __restrict__ err) {
     __shared__ int red[16];
     int c = 0;
     const long n = B * S;
@@ -59,7 +59,15 @@ __global__ __launch_bounds__(1024) void ce_count_kernel(const long* __restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long i = i0 + 1024 * u;
-            if (i < n && (int)(i % S) + 1 < S && lab[u] != ignore_index) ++c;
+            if (i < n && (int)(i % S) + 1 < S && lab[u] != ignore_index) {
+                // the same validity test as the loss kernels: a label outside [0, V) scores nothing and is not counted
+                // (the reference asserts on it: bit 2 of the error flag lets the host raise)
+                if (V > 0 && (lab[u] < 0 || lab[u] >= V)) {
+                    if (err) atomicOr(err, 4);
+                } else {
+                    ++c;
+                }
+            }
         }
     }
 #pragma unroll
@@ -241,9 +249,10 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* __restri
 }  // namespace
 
 extern "C" int mgen_ce_count(const long* labels, long B, int S, long ignore_index, float* inv_count, int* count,
-                             hipStream_t stream) {
+                             long V, int* err_flag, hipStream_t stream) {
     MGEN_REQUIRE(labels && inv_count && B > 0 && S > 0, "mgen_ce_count: bad arguments");
-    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, B, S, ignore_index, inv_count, count);
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, stream, labels, B, S, ignore_index, inv_count, count, V,
+                       err_flag);
     return mgen_check_launch("mgen_ce_count");
 }
 

@@ -70,7 +70,24 @@ __global__ __launch_bounds__(256) void collate_pos4d_kernel(const float* __restr
     if (ids) ids[i] = 0;
 }
 
+__global__ __launch_bounds__(256) void right_padding_kernel(const long* __restrict__ mask, int B, int S,
+                                                            int* __restrict__ err) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * S) return;
+    const int s = (int)(i % S);
+    if (s + 1 < S && mask[i] == 0 && mask[i + 1] != 0) atomicOr(err, 2);
+}
+
 }  // namespace
+
+// Sets bit 1 (value 2) of *err_flag if some row of mask [B][S] has a 0 followed by a non-zero (not right padding).
+extern "C" int mgen_check_right_padding(const long* mask, int B, int S, int* err_flag, hipStream_t stream) {
+    MGEN_REQUIRE(mask && err_flag && B > 0 && S > 0, "mgen_check_right_padding: bad arguments");
+    const long n = (long)B * S;
+    hipLaunchKernelGGL(right_padding_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mask, B, S,
+                       err_flag);
+    return mgen_check_launch("mgen_check_right_padding");
+}
 
 // flat: the B examples back to back (int64); offsets[B+1]: where each starts. Outputs [B][S] int64 (S >= the longest
 // example): ids, attention mask (may be null), labels (may be null). mask_pads: labels = -100 on the padding.

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const long* __restri
     for (long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6); t < T; t += (long)gridDim.x * 4) {
         long id = ids[t];
         if (id < 0 || id >= V) {
-            if (lane == 0 && err) atomicExch(err, 1);
+            if (lane == 0 && err) atomicOr(err, 1);
             id = 0;
         }
         const float* src = table + id * d;

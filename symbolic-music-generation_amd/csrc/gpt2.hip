@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void embed_pos_kernel(const long* __restrict__
         long id = ids[t];
         int p = pos ? pos[t] : (int)(t % S);
         if (id < 0 || id >= V || p < 0 || p >= P) {
-            if (lane == 0 && err) *err = 1;
+            if (lane == 0 && err) atomicOr(err, 1);
             id = id < 0 ? 0 : (id >= V ? V - 1 : id);
             p = p < 0 ? 0 : (p >= P ? P - 1 : p);
         }

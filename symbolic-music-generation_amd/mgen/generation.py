@@ -143,6 +143,8 @@ class GenerationMixin:
         dev = input_ids.device
         V = cfg.vocab_size
         total = P + max_new_tokens
+        if self._err_flag is not None:
+            self._err_flag.zero_()   # bits left behind by an earlier call belong to that call
         self.sync_shadow()
         out = torch.empty(B, total, dtype=torch.int64, device=dev)
         out[:, :P] = input_ids
@@ -172,8 +174,7 @@ class GenerationMixin:
                 if unfinished is not None and int(unfinished.max()) == 0:
                     break
             out = out[:, :P + n_done]
-            if self._err_flag is not None and int(self._err_flag) != 0:
-                raise IndexError("token id out of range in generate()")
+            self._check_device_flags()
             return (out, torch.stack(step_logits, 0)) if return_step_logits else out
         cache = KVCache(cfg, B, total, dev)
         buf = _DecodeBuffers(cfg, B, dev)
@@ -220,8 +221,7 @@ class GenerationMixin:
             if bool(all_done.any()):
                 first = int(torch.nonzero(all_done)[0])
                 out = out[:, :P + first + 1]
-        if self._err_flag is not None and int(self._err_flag) != 0:
-            raise IndexError("token id out of range in generate()")
+        self._check_device_flags()
         if return_step_logits:
             return out, torch.stack(step_logits, 0)
         return out

@@ -16,6 +16,7 @@ dgrad/wgrad GEMMs and the fused norm/rope/attention backward kernels.
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -137,8 +138,11 @@ class MidiLM(GenerationMixin, nn.Module):
             self._layers.append(self._make_layer_views(l))
         self._rope_cs = None
         self._rope_npos = 0
-        self._lm_grad_tmp = None
+        self._lm_grad_tmp = None       # head weight gradient of the one forward that owns it (see _head_grad_buffer)
+        self._lm_grad_owner = None
         self.lora = None        # low-rank adapters (to_lora): then the base weights are frozen
+        # device-side error bits raised by kernels: 1 = token id out of range, 2 = attention_mask is not right
+        # padding, 4 = label outside [0, V). Read (one synchronisation) and cleared by _check_device_flags.
         self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
         if seed is not None:
             self.init_weights(seed)
@@ -160,6 +164,38 @@ class MidiLM(GenerationMixin, nn.Module):
             self._rope4d_f = None
         elif cfg.tie_word_embeddings:
             _register(self, "lm_head.weight", self.model.embed_tokens.weight)
+
+    def _check_device_flags(self):
+        """Raise what the reference raises at the faulty call: its embedding lookup fails on a token id outside the
+        vocabulary and its cross entropy on a label outside it (both device-side asserts there); an attention_mask
+        other than right padding would need masked attention, which this path does not compute. The kernels keep
+        going with a clamped id / an ignored label, so the check may come later than the fault: after backward, at
+        the end of an evaluation forward and of generate()."""
+        if self._err_flag is None:
+            return
+        bits = int(self._err_flag)
+        if bits == 0:
+            return
+        self._err_flag.zero_()
+        if bits & 1:
+            raise IndexError("token id out of range [0, vocab_size)")
+        if bits & 4:
+            raise IndexError("label outside [0, vocab_size) that is not ignore_index (-100)")
+        raise ValueError("attention_mask must be right padding (ones followed by zeros in every row): causal "
+                         "attention then needs no mask for the real tokens; other masks are not supported")
+
+    def _head_grad_buffer(self, shape, token):
+        """fp32 buffer for the head's weight gradient, formed during forward and added to the gradient in
+        backward. One buffer is kept on the model and lent to one autograd graph at a time; a forward that starts
+        while the previous graph has not run its backward yet (two losses summed before one backward) gets a
+        buffer of its own."""
+        owner = self._lm_grad_owner() if self._lm_grad_owner is not None else None
+        if owner is not None and not owner.done:
+            return torch.empty(shape, dtype=torch.float32, device=self.flat_param.device)
+        if self._lm_grad_tmp is None or tuple(self._lm_grad_tmp.shape) != tuple(shape):
+            self._lm_grad_tmp = torch.empty(shape, dtype=torch.float32, device=self.flat_param.device)
+        self._lm_grad_owner = weakref.ref(token)
+        return self._lm_grad_tmp
 
     def _anchor(self):
         """A parameter handed to the autograd node so that it has a differentiable input."""
@@ -330,9 +366,10 @@ class MidiLM(GenerationMixin, nn.Module):
     # ------------------------------------------------------------------------------------------------
     def forward(self, input_ids=None, attention_mask=None, labels=None, num_logits_to_keep: int = 0,
                 position_tensors=None, **unused):
-        """attention_mask is accepted for call compatibility. With right padding (what the reference's collators
-        produce) causal attention already keeps real tokens from seeing pads, so loss and gradients do not depend
-        on it; logits at pad positions are unspecified."""
+        """attention_mask: with right padding (what the reference's collators produce) causal attention already keeps
+        real tokens from seeing pads, so loss and gradients do not depend on it and logits at pad positions are
+        unspecified; any other mask raises ValueError (checked on the device, reported after backward or at the end
+        of an evaluation forward)."""
         if self.cfg.pos4d:
             return self._forward_pos4d(position_tensors, labels)
         if input_ids is None:
@@ -344,6 +381,11 @@ class MidiLM(GenerationMixin, nn.Module):
         input_ids = input_ids.contiguous()
         if labels is not None:
             labels = labels.contiguous().to(torch.int64)
+        if attention_mask is not None:
+            if tuple(attention_mask.shape) != tuple(input_ids.shape):
+                raise ValueError("attention_mask must have the shape of input_ids")
+            ops.check_right_padding(attention_mask.to(device=input_ids.device, dtype=torch.int64).contiguous(),
+                                    self._err_flag)
         self.sync_shadow()
         if self.lora is not None:
             self.lora.sync_shadow()
@@ -355,11 +397,13 @@ class MidiLM(GenerationMixin, nn.Module):
             loss = None
             if labels is not None:
                 loss, _ = self._lm_head_loss(hN, labels, with_grad=False)
+                self._check_device_flags()
                 return CausalLMOutput(loss=loss, logits=None)
             B, S = input_ids.shape
             if num_logits_to_keep:
                 hN = hN.view(B, S, -1)[:, -num_logits_to_keep:, :].reshape(-1, hN.shape[-1]).contiguous()
             logits = self._logits(hN).view(B, -1, self.cfg.vocab_size)
+            self._check_device_flags()
             return CausalLMOutput(loss=None, logits=logits)
 
     def _forward_pos4d(self, position_tensors, labels):
@@ -385,10 +429,10 @@ class MidiLM(GenerationMixin, nn.Module):
                 loss, _ = self._cos_head_loss(xN, labels, with_grad=False)
         return CausalLMOutput(loss=loss, logits=self._last_pred.view(B, S, 8, 2))
 
-    def _cos_head_loss(self, xN, labels, with_grad: bool):
+    def _cos_head_loss(self, xN, labels, with_grad: bool, grad_buf=None):
         """16-wide head, unit-normalised pairs (kept in self._last_pred, fp32 [T,16]) and the cosine loss. With
-        with_grad, also returns d(loss)/d(xN) (bf16) and leaves d(loss)/d(W_head) in self._lm_grad_tmp, both for
-        upstream grad 1."""
+        with_grad, also returns d(loss)/d(xN) (bf16) and leaves d(loss)/d(W_head) in grad_buf ([16, d] fp32), both
+        for upstream grad 1."""
         cfg = self.cfg
         T, d = xN.shape[0], cfg.hidden_size
         dev = xN.device
@@ -413,17 +457,18 @@ class MidiLM(GenerationMixin, nn.Module):
             dxN = torch.empty(T, d, dtype=self.act_dtype, device=dev)
             dps = ops.presplit(dpairs)
             ops.gemm_any(dps, W, dxN, T, d, POS4D_HEAD_OUT, POS4D_HEAD_OUT, W.stride(0), d, False, True, ops.OUT_BF16)
-            if self._lm_grad_tmp is None:
-                self._lm_grad_tmp = torch.empty(POS4D_HEAD_OUT, d, dtype=torch.float32, device=dev)
-            self._lm_grad_tmp.zero_()   # accumulate mode lets the [16, d] output use the split-K path over T
-            ops.gemm_any(dps, xN, self._lm_grad_tmp, POS4D_HEAD_OUT, d, T, POS4D_HEAD_OUT, xN.stride(0), d, True, True,
+            grad_buf.zero_()   # accumulate mode lets the [16, d] output use the split-K path over T
+            ops.gemm_any(dps, xN, grad_buf, POS4D_HEAD_OUT, d, T, POS4D_HEAD_OUT, xN.stride(0), d, True, True,
                          ops.OUT_F32_ACC)
         return loss, dxN
 
-    def _head_loss(self, xN, labels, with_grad: bool):
+    def _head_grad_shape(self):
+        return (POS4D_HEAD_OUT if self.cfg.pos4d else self.cfg.vocab_size, self.cfg.hidden_size)
+
+    def _head_loss(self, xN, labels, with_grad: bool, grad_buf=None):
         if self.cfg.pos4d:
-            return self._cos_head_loss(xN, labels, with_grad)
-        return self._lm_head_loss(xN, labels, with_grad)
+            return self._cos_head_loss(xN, labels, with_grad, grad_buf)
+        return self._lm_head_loss(xN, labels, with_grad, grad_buf)
 
     def _logits(self, hN):
         cfg = self.cfg
@@ -522,9 +567,10 @@ class MidiLM(GenerationMixin, nn.Module):
         ops.rmsnorm_fwd(h, self.model.norm.weight, xN, rstdN, cfg.rms_norm_eps)
         return xN, (h, rstdN, cs)
 
-    def _lm_head_loss(self, xN, labels, with_grad: bool):
+    def _lm_head_loss(self, xN, labels, with_grad: bool, grad_buf=None):
         """Fused lm_head + shifted cross entropy over chunks of tokens. With with_grad, also returns
-        d(loss)/d(xN) (bf16) and leaves d(loss)/d(W_lm_head) in self._lm_grad_tmp (fp32), both for upstream grad 1."""
+        d(loss)/d(xN) (bf16) and leaves d(loss)/d(W_lm_head) in grad_buf ([V, d] fp32; not needed with adapters),
+        both for upstream grad 1."""
         cfg = self.cfg
         B, S = labels.shape
         T = B * S
@@ -534,13 +580,10 @@ class MidiLM(GenerationMixin, nn.Module):
         ld = (V + 7) // 8 * 8
         chunk = min(cfg.lm_head_chunk_tokens, T)
         inv_count = torch.empty(1, dtype=torch.float32, device=dev)
-        ops.ce_count(labels, inv_count)
+        ops.ce_count(labels, inv_count, V=V, err_flag=self._err_flag)
         row_loss = torch.empty(T, dtype=torch.float32, device=dev)
         logits = torch.empty(chunk, ld, dtype=self.act_dtype, device=dev)
         dxN = torch.empty(T, d, dtype=self.act_dtype, device=dev) if with_grad else None
-        if with_grad:
-            if self._lm_grad_tmp is None:
-                self._lm_grad_tmp = torch.empty(V, d, dtype=torch.float32, device=dev)
         first = True
         for t0 in range(0, T, chunk):
             n = min(chunk, T - t0)
@@ -556,13 +599,13 @@ class MidiLM(GenerationMixin, nn.Module):
                 if self.lora is not None:
                     pass   # frozen base: no weight gradient for the head
                 elif isinstance(dl, ops.W2):
-                    ops.gemm_any(dl, xc, self._lm_grad_tmp, V, d, n, ld, xc.stride(0), d, True, True,
+                    ops.gemm_any(dl, xc, grad_buf, V, d, n, ld, xc.stride(0), d, True, True,
                                  ops.OUT_F32 if first else ops.OUT_F32_ACC)
                     first = False
                 else:
                     for r0 in range(0, n, 8192):
                         rn = min(8192, n - r0)
-                        ops.gemm(dl[r0:r0 + rn], xc[r0:r0 + rn], self._lm_grad_tmp, V, d, rn, ld, xc.stride(0), d,
+                        ops.gemm(dl[r0:r0 + rn], xc[r0:r0 + rn], grad_buf, V, d, rn, ld, xc.stride(0), d,
                                  True, True, ops.OUT_F32 if first else ops.OUT_F32_ACC)
                         first = False
         loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -692,6 +735,13 @@ class MidiLM(GenerationMixin, nn.Module):
         return out
 
 
+class _GraphToken:
+    """Identity of one forward's autograd graph (see MidiLM._head_grad_buffer)."""
+
+    def __init__(self):
+        self.done = False
+
+
 class _LMTrainFunction(torch.autograd.Function):
     """The whole network as one autograd node (see module docstring)."""
 
@@ -699,7 +749,9 @@ class _LMTrainFunction(torch.autograd.Function):
     def forward(ctx, model: MidiLM, input_ids, labels, _anchor):
         saved: list = []
         xN, final = model._run_layers(input_ids, save=saved)
-        loss, dxN = model._head_loss(xN, labels, with_grad=True)
+        ctx.token = _GraphToken()
+        ctx.lm_grad = None if model.lora is not None else model._head_grad_buffer(model._head_grad_shape(), ctx.token)
+        loss, dxN = model._head_loss(xN, labels, with_grad=True, grad_buf=ctx.lm_grad)
         ctx.model, ctx.input_ids, ctx.saved, ctx.final, ctx.dxN = model, input_ids, saved, final, dxN
         return loss
 
@@ -715,11 +767,14 @@ class _LMTrainFunction(torch.autograd.Function):
             ops.scale_(dxN, 1.0, go)
         else:
             ops.scale_bf16_(dxN, 1.0, go)
-        if model.lora is None:   # (frozen base: the head's weight gradient was not formed)
+        if ctx.lm_grad is not None:   # (frozen base: the head's weight gradient was not formed)
             name = model._lm_head_name()
-            ops.axpy_(model._view(model.flat_grad, name).view(-1), model._lm_grad_tmp.view(-1), 1.0, go)
+            ops.axpy_(model._view(model.flat_grad, name).view(-1), ctx.lm_grad.view(-1), 1.0, go)
         model._backward_layers(ctx.input_ids, ctx.saved, ctx.final, dxN, getattr(model, "_grad_hook", None))
         ctx.saved = None
+        ctx.lm_grad = None
+        ctx.token.done = True
+        model._check_device_flags()
         for pname, prm in model.named_parameters():
             if prm.grad is None:
                 prm.grad = model._view(model.flat_grad, pname)

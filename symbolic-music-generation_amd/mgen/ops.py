@@ -405,9 +405,16 @@ def cast(src, dst):
     call("mgen_cast", _p(src), _p(dst), src.numel(), kind, _stream())
 
 
-def ce_count(labels, inv_count, count=None, ignore_index=-100):
+def ce_count(labels, inv_count, count=None, ignore_index=-100, V=0, err_flag=None):
+    """V > 0: labels outside [0, V) are not counted and set bit 2 of err_flag."""
     B, S = labels.shape
-    call("mgen_ce_count", _p(labels), B, S, ignore_index, _p(inv_count), _p(count), _stream())
+    call("mgen_ce_count", _p(labels), B, S, ignore_index, _p(inv_count), _p(count), V, _p(err_flag), _stream())
+
+
+def check_right_padding(mask, err_flag):
+    """Sets bit 1 of err_flag if a row of the int64 mask [B, S] is anything but ones followed by zeros."""
+    B, S = mask.shape
+    call("mgen_check_right_padding", _p(mask), B, S, _p(err_flag), _stream())
 
 
 def ce_fwd_bwd(logits, labels, tok0, rows, V, ld, S, inv_count, grad_scale, row_loss, lse_out=None, write_grad=True,

@@ -46,6 +46,9 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if (getattr(self.model, "lora", None) is not None) != (self.store is not self.model):
+            raise RuntimeError("the model's adapters changed after this optimizer was built (to_lora / merge_lora): "
+                               "build the optimizer after them")
         g = self.param_groups[0]
         self.step_count += 1
         clip = None
@@ -62,6 +65,28 @@ class FusedAdamW(torch.optim.Optimizer):
         self.model.zero_grad()
         if self.store is not self.model:
             self.store.zero_grad()
+
+    # The moments live in two flat buffers outside `self.state` (one kernel updates everything): a checkpoint has
+    # to carry them, the step count (bias correction) and, with adapters, nothing else (the adapter weights are
+    # part of the model's own state). Lightning checkpoints of the reference hold `optimizer_states` the same way.
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused"] = {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                       "step_count": self.step_count, "numel": self.exp_avg.numel()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fused = state_dict.pop("fused", None)
+        super().load_state_dict(state_dict)
+        if fused is None:
+            raise KeyError("FusedAdamW.load_state_dict: the 'fused' entry (moments and step count) is missing")
+        if int(fused["numel"]) != self.exp_avg.numel():
+            raise ValueError("FusedAdamW.load_state_dict: moment buffers of another parameter store "
+                             f"({fused['numel']} elements, this one has {self.exp_avg.numel()})")
+        self.exp_avg.copy_(fused["exp_avg"])
+        self.exp_avg_sq.copy_(fused["exp_avg_sq"])
+        self.step_count = int(fused["step_count"])
 
 
 def get_optim(model, lr, num_epochs, steps_per_epoch, warmup=1000, end_ratio=0.1, max_grad_norm=1.0):

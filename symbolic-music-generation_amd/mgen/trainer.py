@@ -72,6 +72,9 @@ class GradReducer:
             self._flush()
 
     def wait(self):
+        if getattr(self.model, "lora", None) is not self._lora:
+            raise RuntimeError("the model's adapters changed after this reducer was built (to_lora / merge_lora): "
+                               "build the Trainer after them")
         if self._lora is not None and self.world > 1:
             buf = self._lora.flat_grad
             self._pending.append((self._start(buf), buf))
@@ -111,7 +114,13 @@ class Trainer:
         self.model.eval()
         loss = self.model(**batch).loss
         if self.reducer.world > 1:  # self.log(..., sync_dist=True): mean over ranks
-            dist.all_reduce(loss, op=dist.ReduceOp.AVG, group=self.reducer.group)
+            if self.reducer._native_avg:
+                dist.all_reduce(loss, op=dist.ReduceOp.AVG, group=self.reducer.group)
+            else:   # gloo has no AVG
+                loss = loss.clone()
+                host = loss.cpu() if loss.is_cuda else loss
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.reducer.group)
+                loss = (host / self.reducer.world).to(loss.device)
         return loss
 
 

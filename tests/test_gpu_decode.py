@@ -185,6 +185,12 @@ def test_greedy_generate_512_against_oracle(tiny):
     print("greedy tokens identical to the fp32 reference for the first", n_same, "steps")
     if n_same < 512:
         assert float(g["greedy_margin"][n_same]) < 0.1
+    # bf16 against fp32 tokens: identical at least up to the first step whose fp32 top-2 margin is below 0.01 (the
+    # logits are of order 1 to 4, where bf16 resolves 0.008 to 0.03): step 6 for the Llama fixture, never for the
+    # Qwen3 fixture, whose 512 tokens must all match
+    tie = g["greedy_margin"] < 0.01
+    first_tie = int(np.argmax(tie)) if bool(tie.any()) else 512
+    assert n_same >= min(first_tie, 512), (n_same, first_tie)
 
 
 def test_sampled_generate_is_token_exact_given_its_logits(tiny):

@@ -155,6 +155,23 @@ def test_fp32_greedy_512_tokens(tiny32):
         assert g["greedy_margin"][first_bad] < 1e-4, (first_bad, g["greedy_margin"][first_bad])
 
 
+# generate(do_sample=True) without top_k runs with HF's default top_k=50 (the reference's call at
+# src/test_tokenizer.py:129-136 passes no top_k)
+@pytest.mark.parametrize("tag,kw", [("t097_p095", dict(temperature=0.97, top_p=0.95)),
+                                    ("t1_k5_p095", dict(temperature=1.0, top_k=5, top_p=0.95))])
+def test_fp32_sampled_generate_token_exact(tiny32, tag, kw):
+    """Sampled decoding end to end against the tokens the stock transformers generate() produced with the same
+    injected Exp(1) noise (multinomial = argmax p / q): temperature -> top-k -> top-p -> draw, 64 steps, 2 streams."""
+    m, ocfg, g, p = tiny32
+    want = torch.from_numpy(g[f"sample_{tag}/tokens"])
+    steps, B = want.shape[1] - 8, want.shape[0]
+    ng = torch.Generator().manual_seed(int(g[f"sample_{tag}/noise_seed"]))
+    noise = torch.empty(steps, B, ocfg.vocab_size).exponential_(1.0, generator=ng)
+    got = m.generate(want[:, :8].cuda(), max_new_tokens=steps, do_sample=True, noise=noise.cuda(), **kw).cpu()
+    assert got.shape == want.shape
+    assert torch.equal(got, want), (tag, (got != want).nonzero()[:4].tolist())
+
+
 def test_fp32_full_size_decoder_c1():
     """The default decoder at batch 4 x 1024 (the reference's CPU-runnable configuration), scalars and slices."""
     from mgen import MidiLM
@@ -178,3 +195,18 @@ def test_fp32_full_size_decoder_c1():
     with torch.no_grad():
         lg = m(input_ids=ids[:1]).logits[:, ::97, ::1013].cpu().numpy()
     assert rel_err(lg, g["logits_slice"][:1]) < FP32_TOL
+    # the configuration's decode half: 256 greedy tokens from the first 8 ids. Random-init logits are nearly flat
+    # (top-2 margins of 1e-3 and less), so a first difference is accepted only where this path's own top-2 margin
+    # on the reference's prefix is at rounding level; the tokens before it must be identical
+    want = torch.from_numpy(g["greedy_tokens"])
+    assert want.shape == (1, 264) and torch.equal(want[:, :8].cuda(), ids[:1, :8])
+    got = m.generate(ids[:1, :8], max_new_tokens=256, do_sample=False).cpu()
+    same = (got == want)[0, 8:]
+    n_same = int(same.long().cumprod(0).sum())
+    print("full-size greedy: identical for the first", n_same, "of 256 tokens")
+    if n_same < 256:
+        with torch.no_grad():
+            row = m(input_ids=want[:, :8 + n_same].cuda(), num_logits_to_keep=1).logits[0, -1].float()
+        top2 = torch.topk(row, 2).values
+        assert float(top2[0] - top2[1]) < 2e-4 * float(row.abs().max()), (n_same, top2.tolist())
+        assert int(want[0, 8 + n_same]) in torch.topk(row, 2).indices.tolist()

@@ -29,6 +29,31 @@ def test_aria_size_model_trains_at_seq_4096():
     torch.cuda.empty_cache()
 
 
+def test_aria_size_model_full_step_at_seq_16384():
+    """The long-sequence configuration of the benchmark list: one whole training step (forward, backward, clip,
+    AdamW) of the ~650M model on a single 16 384-token sequence. Properties: the initial loss of a random-init
+    network, a finite clipped gradient norm, and the batch being learnt over a few steps."""
+    from mgen import MidiLM, aria_style_llama
+    from mgen.trainer import Trainer
+    cfg = aria_style_llama()
+    assert cfg.max_position_embeddings >= 8192
+    m = MidiLM(cfg, device="cuda:0", seed=0)
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(3, cfg.vocab_size, (1, 16384), generator=g).cuda()
+    lab = ids.clone()
+    lab[0, :4096] = -100                                  # first quarter masked (the prompt span of the collate)
+    tr = Trainer(m, lr=1e-4, num_epochs=1, steps_per_epoch=100, warmup=1, max_grad_norm=1.0)
+    losses = []
+    for _ in range(3):
+        losses.append(float(tr.training_step({"input_ids": ids, "labels": lab})))
+        norm = float(tr.opt.norm_and_coef[0])
+        assert math.isfinite(norm) and norm > 0
+    assert abs(losses[0] - (math.log(cfg.vocab_size) + 0.5 * cfg.hidden_size * 0.02 ** 2)) < 0.05
+    assert all(math.isfinite(x) for x in losses) and losses[-1] < losses[0] - 0.02
+    del tr, m
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("D,H", [(64, 2), (128, 1)])
 def test_attention_at_16384_tokens_matches_fp32_kernel(D, H):
     from mgen import ops
