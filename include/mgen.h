@@ -272,6 +272,11 @@ int mgen_ce_finalize(const float* row_loss, long T, const float* inv_count, floa
 int mgen_sumsq_partial_count(void);
 int mgen_grad_norm_clip(const float* grad, long n, float max_norm, double* workspace, float* out,
                         mgen_stream_t stream);
+/* The same result with NO workspace argument and no allocation (no counterpart in the reference): for callers that
+ * cannot allocate device memory, i.e. code under HIP graph capture, tight serving loops and harnesses that forbid
+ * hipMalloc. The partial sums live in an 8 KiB array inside the code object, one copy per GPU for the life of the
+ * process. n <= 2^36 elements (larger n is rejected). Calls that overlap on one GPU race: serialise them. */
+int mgen_grad_norm_clip_static(const float* grad, long n, float max_norm, float* out, mgen_stream_t stream);
 /* torch.optim.AdamW step (reference src/model/model.py:19-25) over n flat fp32 elements; grad is scaled by clip[1]
  * when clip is given; shadow_bf16 (may be null) receives the rounded new parameters. step is 1-based. */
 int mgen_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, long n,

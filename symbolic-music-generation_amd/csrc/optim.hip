@@ -7,6 +7,7 @@
 // (/root/reference/src/model/model.py:19-25): p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g;
 // p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps).
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -127,6 +128,57 @@ extern "C" int mgen_grad_norm_clip(const float* grad, long n, float max_norm, do
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, stream, grad, n, workspace);
     hipLaunchKernelGGL(clip_finalize_kernel, dim3(1), dim3(256), 0, stream, workspace, (int)nb, max_norm, out);
     return mgen_check_launch("mgen_grad_norm_clip");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same reduction for callers that cannot allocate or bring a workspace (code under HIP graph capture, serving
+// loops, harnesses that forbid hipMalloc): the per-workgroup partial sums go to an array that is part of the code
+// object. Every GPU the library runs on holds its own copy (8 KiB) until the process ends.
+// ---------------------------------------------------------------------------------------------------
+static __device__ __align__(256) double scratch[1024];   // = mgen_sumsq_partial_count() partial sums
+
+namespace {
+constexpr int kMaxDevices = 64;
+constexpr long kStaticMaxN = 1L << 36;   // elements (256 GiB of fp32 gradients): far beyond one GPU's memory
+std::mutex g_scratch_mutex;
+double* g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch` on each device (the name itself is a
+                                           // host-side stand-in: only hipGetSymbolAddress yields the address)
+}  // namespace
+
+// out: 2 floats {norm, clip coefficient}; n <= 2^36. No allocation, no workspace argument. Calls that overlap on one
+// GPU (two streams) race on the partial sums: serialise them. Nothing has to be cleared between calls: every
+// partial the second kernel reads was written by the first kernel of the same call.
+extern "C" int mgen_grad_norm_clip_static(const float* grad, long n, float max_norm, float* out, hipStream_t stream) {
+    MGEN_REQUIRE(grad && out && n > 0, "mgen_grad_norm_clip_static: bad arguments");
+    MGEN_REQUIRE(n <= kStaticMaxN, "mgen_grad_norm_clip_static: n = %ld exceeds the supported maximum of %ld elements",
+                 n, kStaticMaxN);
+    MGEN_REQUIRE(((uintptr_t)grad % 16) == 0, "mgen_grad_norm_clip_static: grad must be 16-byte aligned");
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        mgen_set_error("mgen_grad_norm_clip_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+        return MGEN_ELAUNCH;
+    }
+    double* ws;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {   // once per device, with that device current
+            void* p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !p) {
+                mgen_set_error("mgen_grad_norm_clip_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+                return MGEN_ELAUNCH;
+            }
+            g_scratch_ptr[dev] = static_cast<double*>(p);
+        }
+        ws = g_scratch_ptr[dev];
+    }
+    long nb = (n / 4 + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, stream, grad, n, ws);
+    hipLaunchKernelGGL(clip_finalize_kernel, dim3(1), dim3(256), 0, stream, ws, (int)nb, max_norm, out);
+    return mgen_check_launch("mgen_grad_norm_clip_static");
 }
 
 // n must be a multiple of 4 (the flat store pads every tensor to 64 elements). `step` is 1-based.

@@ -65,6 +65,7 @@ SIGNATURES = {
     "mgen_ce_fwd_bwd": [P, P, L, L, I, L, I, L, P, F, P, P, I, I, P],
     "mgen_ce_finalize": [P, L, P, P, P],
     "mgen_grad_norm_clip": [P, L, F, P, P, P],
+    "mgen_grad_norm_clip_static": [P, L, F, P, P],
     "mgen_adamw_step": [P, P, P, P, P, L, P, F, F, F, F, F, L, P],
     "mgen_scale_f32": [P, L, F, P, P],
     "mgen_axpy_f32": [P, P, L, F, P, P],
