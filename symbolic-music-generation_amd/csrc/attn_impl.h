@@ -985,6 +985,436 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnArgs a) {
     }   // pass (the last step ended with a barrier: both LDS buffers are free again)
 }
 
+// ===================================================================================================
+// backward, part 2 without dropout: dK and dV with 64 keys per wave.
+//
+// In the kernel above every fragment read from LDS feeds one MFMA, which keeps the LDS port as busy as the matrix
+// cores. Here a wave owns 64 keys (two 32-key blocks A and B that share every Q / dO fragment it reads), one wave per
+// SIMD with the whole register file: the dK^T / dV^T accumulators fill the accumulator half (addressed by number, as
+// in the forward kernel), the wave's K rows stay in vector registers as B operands, its V rows are read from a
+// resident LDS image. A workgroup covers 256 keys of one kv head (head_dim 128) or 128 keys of a pair of heads.
+//
+// One unit = 32 queries x 64 keys. Its MFMAs run in the fixed order
+//     P: dP = dO V^T   V: dV^T += dO^T P   K (first part): dK^T += Q^T dS   S: scores of the NEXT unit   K (rest)
+// and the vector work sits between them: the exponentials of the next unit's scores beside K (rest) and the next
+// unit's P, dS = P (dP - delta) beside V. Every MFMA, every vector step and every LDS read is an asm statement or
+// sits between scheduling fences, so this placement is what runs.
+//
+// Q travels through a three-slot ring (the scores of a tile are taken one unit before the tile's other products),
+// dO through a two-slot ring, LSE and delta beside them; one workgroup barrier per 64-query tile, placed between
+// the V and K groups of the tile's second unit: behind it the slots of the tile before (Q) and of this tile (dO)
+// are free and the tile after the next is requested.
+//
+// A wave skips the tiles whose queries all precede its keys (it only takes part in the barrier and the loads);
+// its first tile is the one on its diagonal, computed with the causal mask, as is a last tile that runs past the
+// sequence end.
+// ===================================================================================================
+struct VecStream {   // 64 consecutive floats of a [heads][S] array per wave instruction, by LDS-DMA
+    u32x4 rsrc;
+    int voff;
+    __device__ __forceinline__ void init(const float* base, long nfloats, int lane) {
+        const unsigned long long p = (unsigned long long)base;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)p);
+        rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xFFFFu);
+        rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)(nfloats * 4));
+        rsrc[3] = 0x00020000u;
+        voff = lane * 4;
+    }
+    // floats [elem0, elem0 + 64) -> 256 bytes at LDS byte address lds_dst (past the array's end: zeros)
+    __device__ __forceinline__ void issue(long elem0, unsigned lds_dst) const {
+        unsigned keep;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+        const int soff = __builtin_amdgcn_readfirstlane((int)(elem0 * 4));
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    }
+};
+
+// d(v) (+)= A(v) * B(v): score and dP chains
+__device__ __forceinline__ void mfma_vv0(f32x16& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_vv(f32x16& d, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ float a_sub(float x, float y) {
+    float d; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d;
+}
+__device__ __forceinline__ float a_mul(float x, float y) {
+    float d; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d;
+}
+
+// The lane index from an asm statement: what is derived from it is computed where it is used, not carried in
+// registers from the kernel's start (through loops that have no registers to spare).
+__device__ __forceinline__ int fresh_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+template <int HD> struct Dkv64 {
+    static constexpr int KROWS = HD == 128 ? 256 : 128;   // keys of one head per workgroup
+    static constexpr int NVT = KROWS / 64;                // 64-row tiles of the resident V image
+    static constexpr int HPB = HD == 128 ? 1 : 2;
+    static constexpr int VRES = 0, DORING = NVT * TILE, QRING = DORING + 2 * TILE, LSER = QRING + 3 * TILE;
+    static constexpr int VECB = 64 * HPB * 4;             // bytes of one LSE / delta slot
+    static constexpr int DELR = LSER + 3 * VECB;
+    static constexpr int LDS_BYTES = DELR + 2 * VECB;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
+    using G = Geo<HD>;
+    using L = Dkv64<HD>;
+    constexpr int KS = G::KS, DB = G::DB;
+    constexpr int DVACC = 0, DKACC = 2 * DB * 16;         // accumulator registers: dV^T[db][blk] tiles, then dK^T
+    // MFMA slots of one unit
+    constexpr int NP = 2 * KS, NV = 4 * DB, NS = 2 * KS, NK = 4 * DB, KH = NK / 4;
+    constexpr int pV = NP, pK0 = pV + NV, pS = pK0 + KH, pK1 = pS + NS, NU = pK1 + NK - KH;
+    constexpr int LEAD = 4, LEADS = KH < 4 ? KH : 4;      // slots between an LDS read and its MFMA
+    // vector steps: exponentials (34 steps: multiply-add of element n, exponential of n - 1, packing of pairs)
+    constexpr int NV1 = 34, W1A = NU - (pS + NS + 1), W1B = NP - 1, N1A = NV1 * W1A / (W1A + W1B);
+    constexpr int NV2 = 34, W2 = NV - 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    asm volatile("" ::: "a255");   // the kernel allocates all accumulator registers; the compiler uses none of them
+
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Coords bid = block_coords(a);
+    const int npass = bid.x < a.nqb - 1 - bid.x ? 2 : 1;
+    const int b = bid.z;
+    const int sub = HD == 128 ? 0 : (wave >> 1);
+    const int wk = HD == 128 ? wave : (wave & 1);
+    const int kvh = HD == 128 ? bid.y : 2 * bid.y + sub;
+    const int ks0 = 4 * sub, db0 = 2 * sub;
+    const int S = a.S;
+    const long tok0 = (long)b * S;
+    const int group = HD == 128 ? a.H / a.KVH : 1;
+    const float sl2 = a.scale * LOG2E;
+    const int hq_first = HD == 128 ? bid.y * group : 2 * bid.y;
+    const int kv_row = HD == 128 ? bid.y : 2 * bid.y;    // first kv head of the V tile row
+    TileStream<4> Qs, dOs;
+    Qs.init(a.Q + tok0 * a.sq + (long)hq_first * HD, a.sq, S, wave, lane, HD == 128 ? group * 256 : 256);
+    dOs.init(a.dO + tok0 * a.sdo + (long)hq_first * HD, a.sdo, S, wave, lane, HD == 128 ? group * 256 : 256);
+    VecStream Ls, Ds;
+    const int nheads_row = HD == 128 ? group : 2;
+    Ls.init(a.LSE + ((long)b * a.H + hq_first) * S, (long)nheads_row * S, lane);
+    Ds.init(a.Delta + ((long)b * a.H + hq_first) * S, (long)nheads_row * S, lane);
+    const unsigned lds0 = lds_addr(smem);
+
+    // per-lane LDS offsets; a ring slot's base is added and the k-step / d-block enters by XOR (see row_frag_off)
+    const int rrow = row_frag_off(ks0, lane);
+    const int ccol = col_frag_off(db0, false, lane);
+    const int aV = rrow + L::VRES + wk * TILE;
+    const int vecoff = 16 * hh + 256 * sub;
+    const int kwl = 64 * wk + (lane & 31) - 4 * hh;      // + k0: block A's key of this lane, minus the lane half's row offset
+
+    for (int pass = 0; pass < npass; ++pass) {
+    const int kb = pass == 0 ? bid.x : a.nqb - 1 - bid.x;
+    const int k0 = kb * L::KROWS, kw0 = k0 + 64 * wk;
+    const int t_first = k0 / 64, t_end = (S + 63) / 64;
+    const int per_head = t_end - t_first;
+    const int nsteps = per_head * group;
+    const int skipn = kw0 < S ? wk : per_head;           // tiles of a head sweep before this wave's diagonal tile
+
+    auto issue_step = [&](int s) __attribute__((always_inline)) {
+        const int hrel = HD == 128 ? s / per_head : 0;
+        const int qt0 = (t_first + s % per_head) * 64;
+        const unsigned q3 = (unsigned)(s % 3), d2 = (unsigned)(s & 1);
+        Qs.issue(qt0, lds0 + L::QRING + q3 * TILE, wave, hrel * HD * 2);
+        dOs.issue(qt0, lds0 + L::DORING + d2 * TILE, wave, hrel * HD * 2);
+        if (wave < L::HPB) Ls.issue((long)(hrel + wave) * S + qt0, lds0 + L::LSER + q3 * L::VECB + wave * 256);
+        else if (wave >= 2 && wave < 2 + L::HPB)
+            Ds.issue((long)(hrel + wave - 2) * S + qt0, lds0 + L::DELR + d2 * L::VECB + (wave - 2) * 256);
+    };
+    {
+        TileStream<4> Vs;
+        Vs.init(a.V + tok0 * a.sv + (long)kv_row * HD, a.sv, S, wave, fresh_lane());
+#pragma unroll
+        for (int t = 0; t < L::NVT; ++t) Vs.issue(k0 + 64 * t, lds0 + L::VRES + t * TILE, wave);
+    }
+    issue_step(0);
+    if (nsteps > 1) issue_step(1);
+
+    bf16x8 kf[2][KS];
+    {
+        const int lp = fresh_lane();
+        load_own_rows<KS>(kf[0], a.K + (long)kvh * HD, a.sk, tok0, kw0, S, lp);
+        load_own_rows<KS>(kf[1], a.K + (long)kvh * HD, a.sk, tok0, kw0 + 32, S, lp);
+    }
+    static_for<4 * DB * 16>([&](auto ic) { acc_write<decltype(ic)::value>(0.f); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    settle_frags<KS>(kf[0]);
+    settle_frags<KS>(kf[1]);
+
+    // ---- state of the pipeline
+    f32x16 sc[2], dp[2];                 // scores of the unit whose exponentials are in progress; dP of the current unit
+    float xs[32], ps[32], ts[32], dsv[32];
+    unsigned pw[16], dw[16];             // packed P and dS fragments: fragment (blk, half) = words 4 (2 blk + half) ..
+    f32x4 lv[4], dl[4];                  // LSE / delta of 4 query rows each
+    float nlg[4];
+    int thrA[2], thrS = 0;               // causal / sequence-end thresholds of the unit whose exponentials are in progress
+    thrA[0] = thrA[1] = 0;
+    const float neg_big = NEG_BIG;
+    bf16x8 fD[KS], fVA[KS], fVB[KS], fDT[2 * DB], fQn[KS], fQT[2 * DB];
+
+    // element e of a unit, in the order both vector stages walk: row group g4 = e / 8, block (e / 4) % 2,
+    // register 4 g4 + e % 4 of the block's tile; its packed word
+    auto widx = [](int e) constexpr { return (((e >> 2) & 1) * 2 + (e >> 4)) * 4 + 2 * ((e >> 3) & 1) + ((e & 3) >> 1); };
+
+    auto read_lse = [&](auto gc, int lseb, int un) {
+        constexpr int g4 = decltype(gc)::value;
+        lv[g4] = *reinterpret_cast<const f32x4*>(smem + lseb + vecoff + 128 * un + 32 * g4);
+    };
+    auto read_delta = [&](auto gc, int delb, int u) {
+        constexpr int g4 = decltype(gc)::value;
+        dl[g4] = *reinterpret_cast<const f32x4*>(smem + delb + vecoff + 128 * u + 32 * g4);
+    };
+    // exponential stage, step n in [0, NV1): p = exp2(s * scale * log2 e - lse * log2 e)
+    auto v1_step = [&](auto nc, auto maskc, int lseb, int un) {
+        constexpr int n = decltype(nc)::value;
+        constexpr bool MASKED = decltype(maskc)::value;
+        if constexpr (n < 32) {
+            constexpr int e = n, g4 = e >> 3, blk = (e >> 2) & 1, i = e & 3, r = 4 * g4 + i;
+            if constexpr ((e & 7) == 0 && g4 + 1 < 4) read_lse(std::integral_constant<int, g4 + 1>{}, lseb, un);
+            if constexpr (blk == 0) nlg[i] = a_mul(lv[g4][i], -LOG2E);
+            float x = a_fma(sc[blk][r], sl2, nlg[i]);
+            if constexpr (MASKED) {   // hidden when c_r < thrA (key after query) or c_r >= thrS (query past the end)
+                constexpr int c = (r & 3) + 8 * (r >> 2);
+                asm volatile("v_cmp_lt_i32_e32 vcc, %2, %3\n\tv_cndmask_b32_e32 %0, %0, %1, vcc\n\t"
+                             "v_cmp_ge_i32_e32 vcc, %2, %4\n\tv_cndmask_b32_e32 %0, %0, %1, vcc"
+                             : "+v"(x) : "v"(neg_big), "n"(c), "v"(thrA[blk]), "v"(thrS) : "vcc");
+            }
+            xs[e] = x;
+        }
+        if constexpr (n >= 1 && n < 33) ps[n - 1] = a_exp2(xs[n - 1]);
+        if constexpr (n >= 3 && (n & 1)) {
+            if constexpr (n == 33) asm volatile("s_nop 0");   // the exponential right before this statement
+            pw[widx(n - 3)] = a_cvt_pk_bf16(ps[n - 3], ps[n - 2]);
+        }
+    };
+    // dS stage, step n in [0, NV2): dS = P (dP - delta)
+    auto v2_step = [&](auto nc, int delb, int u) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (n < 32) {
+            constexpr int e = n, g4 = e >> 3, blk = (e >> 2) & 1, i = e & 3, r = 4 * g4 + i;
+            if constexpr ((e & 7) == 0 && g4 + 1 < 4) read_delta(std::integral_constant<int, g4 + 1>{}, delb, u);
+            ts[e] = a_sub(dp[blk][r], dl[g4][i]);
+        }
+        if constexpr (n >= 1 && n < 33) dsv[n - 1] = a_mul(ps[n - 1], ts[n - 1]);
+        if constexpr (n >= 2 && (n & 1) == 0) dw[widx(n - 2)] = a_cvt_pk_bf16(dsv[n - 2], dsv[n - 1]);
+    };
+    auto frag_of = [&](const unsigned (&w)[16], int f) {
+        const u32x4 v = {w[4 * f], w[4 * f + 1], w[4 * f + 2], w[4 * f + 3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto set_thr = [&](int qt0, int un) {
+        thrA[0] = k0 + kwl - qt0 - 32 * un;
+        thrA[1] = thrA[0] + 32;
+        thrS = S - qt0 - 32 * un - 4 * hh;
+    };
+    // fragments the P group of a unit needs before its first slots (read at the end of the unit before)
+    auto read_p_head = [&](auto ic, int aD, int u) {
+        constexpr int i = decltype(ic)::value;   // 0: dO[0], V_A[0]; 1: V_B[0]; 2: dO[1], V_A[1]
+        if constexpr (i == 0) { fD[0] = lds_read_b128(smem, aD + 8192 * u); fVA[0] = lds_read_b128(smem, aV); }
+        if constexpr (i == 1) fVB[0] = lds_read_b128(smem, aV + 8192);
+        if constexpr (i == 2) {
+            fD[1] = lds_read_b128(smem, (aD ^ 32) + 8192 * u);
+            fVA[1] = lds_read_b128(smem, aV ^ 32);
+        }
+    };
+
+    int s = 0;   // step = 64-query tile of one query head
+    auto sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 2 < nsteps) issue_step(s + 2);
+    };
+
+    // One unit. U: which half of the tile; M_CUR / M_NEXT: the unit's / the next unit's exponentials take the masks;
+    // HAS_NEXT: there is a next unit in this head sweep. Ring bases are LDS byte offsets of this step's (and, for the
+    // second unit, the next step's) slots.
+    auto unit = [&](auto uc, auto mcurc, auto mnextc, auto hasc, int dob, int dob_n, int qb, int qb_n, int lseb,
+                    int lseb_n, int delb, int qt0_c, int qt0_n) __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value, UN = U ^ 1;
+        constexpr bool HAS_NEXT = decltype(hasc)::value;
+        if constexpr (decltype(mcurc)::value) set_thr(qt0_c, U);
+        const int aD = rrow + dob, cD = ccol + dob, cQ = ccol + qb, aQn = rrow + qb_n, aDn = rrow + dob_n;
+        static_for<NU>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            // ---- the slot's MFMA
+            if constexpr (g < pV) {
+                constexpr int ks = g >> 1, blk = g & 1;
+                if constexpr (ks == 0) mfma_vv0(dp[blk], fD[ks], blk ? fVB[ks] : fVA[ks]);
+                else mfma_vv(dp[blk], fD[ks], blk ? fVB[ks] : fVA[ks]);
+            } else if constexpr (g < pK0) {
+                constexpr int v = g - pV, i = v >> 1, blk = v & 1, db = i >> 1, half = i & 1;
+                mfma_acc<DVACC + (db * 2 + blk) * 16>(fDT[i], frag_of(pw, blk * 2 + half));
+            } else if constexpr (g < pS || g >= pK1) {
+                constexpr int k = g < pS ? g - pK0 : g - pK1 + KH, i = k >> 1, blk = k & 1, db = i >> 1, half = i & 1;
+                mfma_acc<DKACC + (db * 2 + blk) * 16>(fQT[i], frag_of(dw, blk * 2 + half));
+            } else if constexpr (HAS_NEXT) {
+                constexpr int sidx = g - pS, ks = sidx >> 1, blk = sidx & 1;
+                if constexpr (ks == 0) mfma_vv0(sc[blk], fQn[ks], kf[blk][ks]);
+                else mfma_vv(sc[blk], fQn[ks], kf[blk][ks]);
+            }
+            // ---- LDS reads for later slots
+            static_for<KS>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (ks >= 2 && g == 2 * ks - 3) {
+                    fD[ks] = lds_read_b128(smem, (aD ^ (32 * ks)) + 8192 * U);
+                    fVA[ks] = lds_read_b128(smem, aV ^ (32 * ks));
+                }
+                if constexpr (ks >= 1 && g == 2 * ks - 2) fVB[ks] = lds_read_b128(smem, (aV ^ (32 * ks)) + 8192);
+                if constexpr (HAS_NEXT && g == pS + 2 * ks - LEADS)
+                    fQn[ks] = lds_read_b128(smem, (aQn ^ (32 * ks)) + 8192 * UN);
+            });
+            static_for<2 * DB>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, db = i >> 1, half = i & 1;
+                constexpr int im = 8192 * U + 4096 * half;
+                if constexpr (g == pV + 2 * i - LEAD) {
+                    const int x = cD ^ (64 * db);
+                    fDT[i] = col_frag(smem, x + im, (x ^ 32) + 2048 + im);
+                }
+                constexpr int ck = 2 * i < KH ? pK0 + 2 * i : pK1 + 2 * i - KH;
+                if constexpr (g == ck - LEAD) {
+                    const int x = cQ ^ (64 * db);
+                    fQT[i] = col_frag(smem, x + im, (x ^ 32) + 2048 + im);
+                }
+            });
+            if constexpr (HAS_NEXT && g >= NU - 3) read_p_head(std::integral_constant<int, g - (NU - 3)>{}, aDn, UN);
+            // ---- vector steps
+            if constexpr (g < W1B) {          // rest of this unit's exponentials
+                constexpr int lo = N1A + g * (NV1 - N1A) / W1B, hi = N1A + (g + 1) * (NV1 - N1A) / W1B;
+                static_for<hi - lo>([&](auto ic) {
+                    v1_step(std::integral_constant<int, lo + decltype(ic)::value>{}, mcurc, lseb, U);
+                });
+            }
+            if constexpr (g == pV) read_delta(std::integral_constant<int, 0>{}, delb, U);
+            if constexpr (g >= pV + 2 && g < pK0) {   // dS of this unit
+                constexpr int w = g - (pV + 2), lo = w * NV2 / W2, hi = (w + 1) * NV2 / W2;
+                static_for<hi - lo>([&](auto ic) {
+                    v2_step(std::integral_constant<int, lo + decltype(ic)::value>{}, delb, U);
+                });
+            }
+            if constexpr (HAS_NEXT && g == pS + NS - 1) {
+                read_lse(std::integral_constant<int, 0>{}, lseb_n, UN);
+                if constexpr (decltype(mnextc)::value) set_thr(qt0_n, UN);
+            }
+            if constexpr (HAS_NEXT && g > pS + NS) {   // first part of the next unit's exponentials
+                constexpr int w = g - (pS + NS + 1), lo = w * N1A / W1A, hi = (w + 1) * N1A / W1A;
+                static_for<hi - lo>([&](auto ic) {
+                    v1_step(std::integral_constant<int, lo + decltype(ic)::value>{}, mnextc, lseb_n, UN);
+                });
+            }
+            if constexpr (U == 1 && g == pK0 - 1) sync();
+            SCHED_FENCE();
+        });
+    };
+    // what the unit before would have left behind for a wave's first unit of a head sweep: the unit's scores, the first
+    // part of its exponentials and the first P-group fragments
+    auto prologue = [&](int dob, int qb, int lseb, int qt0) __attribute__((always_inline)) {
+        const int aQ = rrow + qb;
+        static_for<KS>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            const bf16x8 f = lds_read_b128(smem, aQ ^ (32 * ks));
+            if constexpr (ks == 0) { mfma_vv0(sc[0], f, kf[0][ks]); mfma_vv0(sc[1], f, kf[1][ks]); }
+            else { mfma_vv(sc[0], f, kf[0][ks]); mfma_vv(sc[1], f, kf[1][ks]); }
+        });
+        read_lse(std::integral_constant<int, 0>{}, lseb, 0);
+        set_thr(qt0, 0);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        SCHED_FENCE();
+        static_for<N1A>([&](auto nc) { v1_step(nc, std::true_type{}, lseb, 0); });
+        static_for<3>([&](auto ic) { read_p_head(ic, rrow + dob, 0); });
+        SCHED_FENCE();
+    };
+
+    const std::integral_constant<int, 0> U0;
+    const std::integral_constant<int, 1> U1;
+    const std::true_type T;
+    const std::false_type F;
+    // One step = the two units of a tile. A body that applies masks computes the thresholds of the unit it applies
+    // them to, so masks may be on for a unit that needs none (slower, same result); a unit that needs them must have
+    // them on in both bodies that carry its exponentials (the first part runs in the unit before).
+    //   MASKED  masks on for this tile and for the start of the next one
+    //   PLAIN   no masks
+    //   LAST    masks on, last tile of the head sweep
+    auto step = [&](auto kindc, int jt) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kindc)::value;
+        const int q3 = s % 3, q3n = (s + 1) % 3, d2 = s & 1;
+        const int dob = L::DORING + d2 * TILE, dobn = L::DORING + (d2 ^ 1) * TILE;
+        const int qb = L::QRING + q3 * TILE, qbn = L::QRING + q3n * TILE;
+        const int lseb = L::LSER + q3 * L::VECB, lsebn = L::LSER + q3n * L::VECB;
+        const int delb = L::DELR + d2 * L::VECB;
+        const int qt0 = (t_first + jt) * 64;
+        if constexpr (KIND == 0) {
+            unit(U0, T, T, T, dob, dob, qb, qb, lseb, lseb, delb, qt0, qt0);
+            unit(U1, T, T, T, dob, dobn, qb, qbn, lseb, lsebn, delb, qt0, qt0 + 64);
+        } else if constexpr (KIND == 1) {
+            unit(U0, F, F, T, dob, dob, qb, qb, lseb, lseb, delb, qt0, qt0);
+            unit(U1, F, F, T, dob, dobn, qb, qbn, lseb, lsebn, delb, qt0, qt0 + 64);
+        } else {
+            unit(U0, T, T, T, dob, dob, qb, qb, lseb, lseb, delb, qt0, qt0);
+            unit(U1, T, F, F, dob, dobn, qb, qbn, lseb, lsebn, delb, qt0, qt0 + 64);
+        }
+        ++s;
+    };
+    const std::integral_constant<int, 0> MASKED;
+    const std::integral_constant<int, 1> PLAIN;
+    const std::integral_constant<int, 2> LAST;
+    // tiles of a head sweep for this wave: skipped ones, the diagonal tile (masked), plain tiles, a masked tile in front
+    // of a last tile that runs past the sequence end, the last tile
+    const int plain_end = per_head - 1 - ((S & 63) != 0 ? 1 : 0);
+    for (int hq = 0; hq < group; ++hq) {
+        for (int jt = 0; jt < skipn; ++jt, ++s) sync();
+        if (skipn < per_head) {
+            int jt = skipn;
+            prologue(L::DORING + (s & 1) * TILE, L::QRING + (s % 3) * TILE, L::LSER + (s % 3) * L::VECB, (t_first + jt) * 64);
+            if (jt < per_head - 1) {
+                step(MASKED, jt);
+                ++jt;
+                for (; jt < plain_end; ++jt) step(PLAIN, jt);
+                for (; jt < per_head - 1; ++jt) step(MASKED, jt);
+            }
+            step(LAST, jt);
+        }
+    }
+
+    // ---- epilogue: dV^T and dK^T leave through LDS (8 KiB of the dO ring per wave, one 32-key block at a time) as
+    // whole rows. The dO ring is free: every wave's last reads of it precede the last barrier.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    char* obuf = smem + L::DORING + wave * 8192;
+    const int le = fresh_lane(), he = le >> 5;
+    static_for<4>([&](auto oc) {
+        constexpr int which = decltype(oc)::value >> 1, blk = decltype(oc)::value & 1;   // 0: dV, 1: dK
+        const float mul = which ? a.scale : 1.f;
+        static_for<DB * 4>([&](auto ic) {
+            constexpr int db = decltype(ic)::value / 4, g4 = decltype(ic)::value % 4;
+            bf16x4 ov;
+            static_for<4>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                ov[e] = (bf16)(acc_read<(which ? DKACC : DVACC) + (db * 2 + blk) * 16 + 4 * g4 + e>() * mul);
+            });
+            *reinterpret_cast<bf16x4*>(obuf + img256_off(le & 31, 4 * (db0 + db) + g4) + 8 * he) = ov;
+        });
+        constexpr int CPR = HD / 8, RPI = 64 / CPR;
+        const int c = le % CPR, r0 = le / CPR;
+        bf16* dst = which ? a.dK : a.dV;
+        const long ld = which ? a.sdk : a.sdv;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int row = i * RPI + r0, key = kw0 + 32 * blk + row;
+            const bf16x8 v = lds_read_b128(obuf, img256_off(row, 4 * db0 + c));
+            if (key < S) *reinterpret_cast<bf16x8*>(dst + (tok0 + key) * ld + (long)kvh * HD + 8 * c) = v;
+        }
+    });
+    __syncthreads();   // the rings and the V image are free for the next pass
+    }   // pass
+}
+
 int check_common(const AttnArgs& a, int head_dim, const char* who) {
     MGEN_REQUIRE(head_dim == 128 || head_dim == 64, "%s: head_dim must be 64 or 128 (got %d)", who, head_dim);
     MGEN_REQUIRE(a.B > 0 && a.S > 0 && a.H > 0 && a.KVH > 0 && a.H % a.KVH == 0, "%s: bad sizes", who);
@@ -1084,15 +1514,27 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* out, 
     aq.nqb = nrb; aq.gx = (nrb + 1) / 2; aq.gy = head_dim == 128 ? H : H / 2; aq.gz = B;
     MGEN_REQUIRE((long)S * sk < (1L << 30) && (long)S * sv < (1L << 30) && (long)S * sq < (1L << 30) &&
                  (long)S * sdo < (1L << 30), "%s: one sequence's Q, K, V or dO exceeds 2 GiB", who);
+    if (!kDrop) {   // 64 keys per wave: key blocks of 256 (head_dim 128) or 128 rows
+        akv.nqb = head_dim == 128 ? (S + 255) / 256 : (S + 127) / 128;
+        akv.gx = (akv.nqb + 1) / 2;
+        static bool asked64[16] = {};
+        if (!asked64[dev]) {
+            if (int e = set_lds(attn_bwd_dkv64_kernel<128>, Dkv64<128>::LDS_BYTES, who)) return e;
+            if (int e = set_lds(attn_bwd_dkv64_kernel<64>, Dkv64<64>::LDS_BYTES, who)) return e;
+            asked64[dev] = true;
+        }
+    }
     const dim3 gkv((unsigned)(akv.gx * akv.gy * akv.gz)), gq((unsigned)(aq.gx * aq.gy * aq.gz));
     // delta = rowsum(dO * O) holds with dropout too: sum_k P dP = sum_k P~ dP~ = dO . O
     if (head_dim == 128) {
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)nb), block, 0, stream, a.O, a.dO, so, sdo, delta, B, S, H);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, kDrop>), gkv, block, 2 * DKV_BUF, stream, akv);
+        if (kDrop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, kDrop>), gkv, block, 2 * DKV_BUF, stream, akv);
+        else hipLaunchKernelGGL(attn_bwd_dkv64_kernel<128>, gkv, block, Dkv64<128>::LDS_BYTES, stream, akv);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<128, kDrop>), gq, block, 4 * TILE, stream, aq);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)nb), block, 0, stream, a.O, a.dO, so, sdo, delta, B, S, H);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, kDrop>), gkv, block, 2 * DKV_BUF, stream, akv);
+        if (kDrop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, kDrop>), gkv, block, 2 * DKV_BUF, stream, akv);
+        else hipLaunchKernelGGL(attn_bwd_dkv64_kernel<64>, gkv, block, Dkv64<64>::LDS_BYTES, stream, akv);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<64, kDrop>), gq, block, 4 * TILE, stream, aq);
     }
     return mgen_check_launch(who);
