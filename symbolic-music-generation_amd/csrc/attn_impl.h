@@ -1415,6 +1415,295 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     }   // pass
 }
 
+// ===================================================================================================
+// backward, part 1 without dropout: dQ with 64 queries per wave (the forward kernel's decomposition).
+//
+// One wave per SIMD; the wave's 64 query rows (blocks A and B) stay in accumulator registers as the B operands of
+// the score products (Q) and of the dP products (dO), next to the dQ^T accumulators, all addressed by number; K and V
+// tiles are streamed. One unit = 32 keys x 64 queries:
+//     P: dP^T = V dO^T        S: scores of the NEXT unit, K Q^T        Q: dQ^T += K^T dS^T
+// with the exponentials of the next unit's scores beside Q and the next unit's P, and dS = P (dP - delta) beside S.
+// K goes through a three-slot ring, V through a two-slot ring, one workgroup barrier per 64-key tile between the P and
+// S groups of the tile's second unit. A wave's last tile is the one on its diagonal (masked); after it the wave only
+// takes part in the barriers and the loads.
+// ===================================================================================================
+template <int HD> struct Dq64 {
+    static constexpr int QROWS = HD == 128 ? 256 : 128;
+    static constexpr int KRING = 0, VRING = 3 * TILE, STG = 5 * TILE;
+    static constexpr int LDS_BYTES = STG + 4 * 8192;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(AttnArgs a) {
+    using G = Geo<HD>;
+    using L = Dq64<HD>;
+    constexpr int KS = G::KS, DB = G::DB;
+    constexpr int DQACC = 0, QACC = 2 * DB * 16, DOACC = QACC + 2 * KS * 4;
+    constexpr int NP = 2 * KS, NS = 2 * KS, NQ = 4 * DB;
+    constexpr int pS = NP, pQ = NP + NS, NU = pQ + NQ;
+    constexpr int LEAD = 4;
+    constexpr int NV1 = 33, W1A = NQ - 1, W1B = NP - 1, N1A = NV1 * W1A / (W1A + W1B);
+    constexpr int NV2 = 34, W2 = NS - 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    asm volatile("" ::: "a255");   // the kernel allocates all accumulator registers; the compiler uses none of them
+
+    const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Coords bid = block_coords(a);
+    const int npass = bid.x < a.nqb - 1 - bid.x ? 2 : 1;
+    const int b = bid.z;
+    const int sub = HD == 128 ? 0 : (wave >> 1);
+    const int wq = HD == 128 ? wave : (wave & 1);
+    const int h = HD == 128 ? bid.y : 2 * bid.y + sub;
+    const int kv_first = HD == 128 ? h / (a.H / a.KVH) : 2 * bid.y;
+    const int ks0 = 4 * sub, db0 = 2 * sub;
+    const int S = a.S;
+    const long tok0 = (long)b * S;
+    const float sl2 = a.scale * LOG2E;
+    TileStream<4> Ks, Vs;
+    Ks.init(a.K + tok0 * a.sk + (long)kv_first * HD, a.sk, S, wave, lane);
+    Vs.init(a.V + tok0 * a.sv + (long)kv_first * HD, a.sv, S, wave, lane);
+    const unsigned lds0 = lds_addr(smem);
+    const int rrow = row_frag_off(ks0, lane);
+    const int ccol = col_frag_off(db0, false, lane);
+    const float neg_big = NEG_BIG;
+
+    for (int pass = 0; pass < npass; ++pass) {
+    const int qb = pass == 0 ? a.nqb - 1 - bid.x : bid.x;
+    const int q0 = qb * L::QROWS, qw0 = q0 + wq * 64;
+    const int J = min(q0 + L::QROWS - 1, S - 1) / 64 + 1;    // tiles the workgroup streams
+    const int jl = qw0 < S ? qw0 / 64 : -1;                  // this wave's last tile, the one on its diagonal
+    const int qrel = qw0 + (lane & 31) - 4 * hh;              // block A's query of this lane minus the lane half's key offset
+
+    auto issue_tile = [&](int j) __attribute__((always_inline)) {
+        Ks.issue(64 * j, lds0 + L::KRING + (unsigned)(j % 3) * TILE, wave);
+        Vs.issue(64 * j, lds0 + L::VRING + (unsigned)(j & 1) * TILE, wave);
+    };
+    issue_tile(0);
+    if (J > 1) issue_tile(1);
+
+    float nl[2], delta[2];
+    {   // the wave's rows of Q and dO -> accumulator registers; LSE and delta of its two rows
+        const int lp = fresh_lane();
+        bf16x8 qf[KS];
+        static_for<4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, which = i >> 1, blk = i & 1;
+            load_own_rows<KS>(qf, (which ? a.dO : a.Q) + (long)h * HD, which ? a.sdo : a.sq, tok0, qw0 + 32 * blk, S, lp);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            static_for<KS * 4>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                const u32x4 v = __builtin_bit_cast(u32x4, qf[w / 4]);
+                const unsigned word = v[w % 4];   // (named: a bit cast applied to a vector element reads element 0)
+                acc_write<(which ? DOACC : QACC) + blk * KS * 4 + w>(__builtin_bit_cast(float, word));
+            });
+        });
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int cq = min(qw0 + 32 * blk + (lp & 31), S - 1);
+            nl[blk] = -a.LSE[((long)b * a.H + h) * S + cq] * LOG2E;
+            delta[blk] = a.Delta[((long)b * a.H + h) * S + cq];
+        }
+    }
+    static_for<2 * DB * 16>([&](auto ic) { acc_write<DQACC + decltype(ic)::value>(0.f); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    asm volatile("" : "+v"(nl[0]), "+v"(nl[1]), "+v"(delta[0]), "+v"(delta[1]));
+
+    // ---- state of the pipeline
+    f32x16 sc[2], dp[2];
+    float xs[32], ps[32], ts[32], dsv[32];
+    unsigned dw[16];
+    int thr[2];
+    thr[0] = thr[1] = 0;
+    bf16x8 fV[KS], fK[KS], fKT[2 * DB];
+
+    // element e: 16-key half e / 16, block (e / 8) % 2, register 8 half + e % 8 of the block's tile
+    auto widx = [](int e) constexpr { return (((e >> 3) & 1) * 2 + (e >> 4)) * 4 + ((e & 7) >> 1); };
+    auto v1_step = [&](auto nc, auto maskc) __attribute__((always_inline)) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (n < 32) {
+            constexpr int e = n, blk = (e >> 3) & 1, r = 8 * (e >> 4) + (e & 7);
+            float x = a_fma(sc[blk][r], sl2, nl[blk]);
+            if constexpr (decltype(maskc)::value) {   // hidden when the key comes after the query: c_r > thr
+                constexpr int c = (r & 3) + 8 * (r >> 2);
+                asm volatile("v_cmp_gt_i32_e32 vcc, %2, %3\n\tv_cndmask_b32_e32 %0, %0, %1, vcc"
+                             : "+v"(x) : "v"(neg_big), "n"(c), "v"(thr[blk]) : "vcc");
+            }
+            xs[e] = x;
+        }
+        if constexpr (n >= 1) ps[n - 1] = a_exp2(xs[n - 1]);
+    };
+    auto v2_step = [&](auto nc) __attribute__((always_inline)) {
+        constexpr int n = decltype(nc)::value;
+        if constexpr (n < 32) {
+            constexpr int e = n, blk = (e >> 3) & 1, r = 8 * (e >> 4) + (e & 7);
+            ts[e] = a_sub(dp[blk][r], delta[blk]);
+        }
+        if constexpr (n >= 1 && n < 33) dsv[n - 1] = a_mul(ps[n - 1], ts[n - 1]);
+        if constexpr (n >= 2 && (n & 1) == 0) dw[widx(n - 2)] = a_cvt_pk_bf16(dsv[n - 2], dsv[n - 1]);
+    };
+    auto frag_of = [&](const unsigned (&w)[16], int f) __attribute__((always_inline)) {
+        const u32x4 v = {w[4 * f], w[4 * f + 1], w[4 * f + 2], w[4 * f + 3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto set_thr = [&](int j, int t) __attribute__((always_inline)) {
+        thr[0] = qrel - 64 * j - 32 * t;
+        thr[1] = thr[0] + 32;
+    };
+    // V fragments of a unit's first P slots (read at the end of the unit before)
+    auto read_v_head = [&](auto ic, int aVt, int t) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        fV[i] = lds_read_b128(smem, (aVt ^ (32 * i)) + 8192 * t);
+    };
+
+    int j = 0;   // tile
+    auto sync = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (j + 2 < J) issue_tile(j + 2);
+    };
+
+    // U: which 32-key half of tile j; M_CUR / M_NEXT: masks on this unit's / the next unit's exponentials
+    auto unit = [&](auto uc, auto mcurc, auto mnextc, auto hasc, int kb, int kb_n, int vb, int vb_n, int j_n)
+                    __attribute__((always_inline)) {
+        constexpr int U = decltype(uc)::value, UN = U ^ 1;
+        constexpr bool HAS_NEXT = decltype(hasc)::value;
+        if constexpr (decltype(mcurc)::value) set_thr(j, U);
+        const int aVc = rrow + vb, aVn = rrow + vb_n, aKn = rrow + kb_n, cK = ccol + kb;
+        static_for<NU>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < pS) {
+                constexpr int ks = g >> 1, blk = g & 1;
+                if constexpr (ks == 0) mfma_vq0<DOACC + (blk * KS + ks) * 4>(dp[blk], fV[ks]);
+                else mfma_vq<DOACC + (blk * KS + ks) * 4>(dp[blk], fV[ks]);
+            } else if constexpr (g < pQ) {
+                if constexpr (HAS_NEXT) {
+                    constexpr int sidx = g - pS, ks = sidx >> 1, blk = sidx & 1;
+                    if constexpr (ks == 0) mfma_vq0<QACC + (blk * KS + ks) * 4>(sc[blk], fK[ks]);
+                    else mfma_vq<QACC + (blk * KS + ks) * 4>(sc[blk], fK[ks]);
+                }
+            } else {
+                constexpr int k = g - pQ, i = k >> 1, blk = k & 1, db = i >> 1, half = i & 1;
+                mfma_acc<DQACC + (blk * DB + db) * 16>(fKT[i], frag_of(dw, blk * 2 + half));
+            }
+            // the tile's barrier: behind the last read of V(j), in front of the first read of K(j + 1)
+            if constexpr (U == 1 && g == NP - 1) sync();
+            // ---- LDS reads for later slots
+            static_for<KS>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                if constexpr (ks >= 2 && g == 2 * ks - LEAD) fV[ks] = lds_read_b128(smem, (aVc ^ (32 * ks)) + 8192 * U);
+                constexpr int want = pS + 2 * ks - LEAD;
+                if constexpr (HAS_NEXT && g == (want < NP - 1 ? NP - 1 : want))
+                    fK[ks] = lds_read_b128(smem, (aKn ^ (32 * ks)) + 8192 * UN);
+            });
+            static_for<2 * DB>([&](auto ic) {
+                constexpr int i = decltype(ic)::value, db = i >> 1, half = i & 1;
+                constexpr int im = 8192 * U + 4096 * half;
+                if constexpr (g == pQ + 2 * i - LEAD) {
+                    const int x = cK ^ (64 * db);
+                    fKT[i] = col_frag(smem, x + im, (x ^ 32) + 2048 + im);
+                }
+            });
+            if constexpr (HAS_NEXT && g >= NU - 2) read_v_head(std::integral_constant<int, g - (NU - 2)>{}, aVn, UN);
+            // ---- vector steps
+            if constexpr (g < W1B) {
+                constexpr int lo = N1A + g * (NV1 - N1A) / W1B, hi = N1A + (g + 1) * (NV1 - N1A) / W1B;
+                static_for<hi - lo>([&](auto ic) {
+                    v1_step(std::integral_constant<int, lo + decltype(ic)::value>{}, mcurc);
+                });
+            }
+            if constexpr (g >= pS + 2 && g < pQ) {
+                constexpr int w = g - (pS + 2), lo = w * NV2 / W2, hi = (w + 1) * NV2 / W2;
+                static_for<hi - lo>([&](auto ic) { v2_step(std::integral_constant<int, lo + decltype(ic)::value>{}); });
+            }
+            if constexpr (HAS_NEXT && decltype(mnextc)::value && g == pQ) set_thr(j_n, UN);
+            if constexpr (HAS_NEXT && g > pQ) {
+                constexpr int w = g - (pQ + 1), lo = w * N1A / W1A, hi = (w + 1) * N1A / W1A;
+                static_for<hi - lo>([&](auto ic) {
+                    v1_step(std::integral_constant<int, lo + decltype(ic)::value>{}, mnextc);
+                });
+            }
+            SCHED_FENCE();
+        });
+    };
+    static_assert(LEAD == 4, "the K reads of the score group start in slot NP - 1, behind the barrier");
+
+    const std::integral_constant<int, 0> U0;
+    const std::integral_constant<int, 1> U1;
+    const std::true_type T;
+    const std::false_type F;
+    // KIND 0: no masks; 1: masks on for this tile and the start of the next; 2: masks on, the wave's last tile
+    auto step = [&](auto kindc) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kindc)::value;
+        const int kb = L::KRING + (j % 3) * TILE, kbn = L::KRING + ((j + 1) % 3) * TILE;
+        const int vb = L::VRING + (j & 1) * TILE, vbn = L::VRING + ((j & 1) ^ 1) * TILE;
+        if constexpr (KIND == 0) {
+            unit(U0, F, F, T, kb, kb, vb, vb, j);
+            unit(U1, F, F, T, kb, kbn, vb, vbn, j + 1);
+        } else if constexpr (KIND == 1) {
+            unit(U0, T, T, T, kb, kb, vb, vb, j);
+            unit(U1, T, T, T, kb, kbn, vb, vbn, j + 1);
+        } else {
+            unit(U0, T, T, T, kb, kb, vb, vb, j);
+            unit(U1, T, F, F, kb, kbn, vb, vbn, j + 1);
+        }
+        ++j;
+    };
+    if (jl >= 0) {
+        {   // what a unit before the first would have left: scores of unit (0, 0), the first part of their
+            // exponentials (masked when tile 0 is the diagonal tile), the first V fragments
+            const int aK = rrow + L::KRING;
+            static_for<KS>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                const bf16x8 f = lds_read_b128(smem, aK ^ (32 * ks));
+                if constexpr (ks == 0) { mfma_vq0<QACC + ks * 4>(sc[0], f); mfma_vq0<QACC + (KS + ks) * 4>(sc[1], f); }
+                else { mfma_vq<QACC + ks * 4>(sc[0], f); mfma_vq<QACC + (KS + ks) * 4>(sc[1], f); }
+            });
+            set_thr(0, 0);
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            SCHED_FENCE();
+            if (jl == 0) static_for<N1A>([&](auto nc) { v1_step(nc, T); });
+            else static_for<N1A>([&](auto nc) { v1_step(nc, F); });
+            static_for<2>([&](auto ic) { read_v_head(ic, rrow + L::VRING, 0); });
+            SCHED_FENCE();
+        }
+        const std::integral_constant<int, 0> PLAIN;
+        const std::integral_constant<int, 1> MASKED;
+        const std::integral_constant<int, 2> LAST;
+        while (j < jl - 1) step(PLAIN);
+        if (j < jl) step(MASKED);
+        step(LAST);
+    }
+    while (j < J) { sync(); ++j; }
+
+    // ---- epilogue: dQ^T leaves through LDS (8 KiB of this wave's own, one 32-row block at a time) as whole rows
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    char* obuf = smem + L::STG + wave * 8192;
+    const int le = fresh_lane(), he = le >> 5;
+    static_for<2>([&](auto bc) {
+        constexpr int blk = decltype(bc)::value;
+        static_for<DB * 4>([&](auto ic) {
+            constexpr int db = decltype(ic)::value / 4, g4 = decltype(ic)::value % 4;
+            bf16x4 ov;
+            static_for<4>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                ov[e] = (bf16)(acc_read<DQACC + (blk * DB + db) * 16 + 4 * g4 + e>() * a.scale);
+            });
+            *reinterpret_cast<bf16x4*>(obuf + img256_off(le & 31, 4 * (db0 + db) + g4) + 8 * he) = ov;
+        });
+        constexpr int CPR = HD / 8, RPI = 64 / CPR;
+        const int c = le % CPR, r0 = le / CPR;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int row = i * RPI + r0, q = qw0 + 32 * blk + row;
+            const bf16x8 v = lds_read_b128(obuf, img256_off(row, 4 * db0 + c));
+            if (q < S) *reinterpret_cast<bf16x8*>(a.dQ + (tok0 + q) * a.sdq + (long)h * HD + 8 * c) = v;
+        }
+    });
+    __syncthreads();   // the rings are free for the next pass
+    }   // pass
+}
+
 int check_common(const AttnArgs& a, int head_dim, const char* who) {
     MGEN_REQUIRE(head_dim == 128 || head_dim == 64, "%s: head_dim must be 64 or 128 (got %d)", who, head_dim);
     MGEN_REQUIRE(a.B > 0 && a.S > 0 && a.H > 0 && a.KVH > 0 && a.H % a.KVH == 0, "%s: bad sizes", who);
@@ -1517,10 +1806,14 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* out, 
     if (!kDrop) {   // 64 keys per wave: key blocks of 256 (head_dim 128) or 128 rows
         akv.nqb = head_dim == 128 ? (S + 255) / 256 : (S + 127) / 128;
         akv.gx = (akv.nqb + 1) / 2;
+        aq.nqb = akv.nqb;   // the dQ kernel's query blocks have the same size
+        aq.gx = akv.gx;
         static bool asked64[16] = {};
         if (!asked64[dev]) {
             if (int e = set_lds(attn_bwd_dkv64_kernel<128>, Dkv64<128>::LDS_BYTES, who)) return e;
             if (int e = set_lds(attn_bwd_dkv64_kernel<64>, Dkv64<64>::LDS_BYTES, who)) return e;
+            if (int e = set_lds(attn_bwd_dq64_kernel<128>, Dq64<128>::LDS_BYTES, who)) return e;
+            if (int e = set_lds(attn_bwd_dq64_kernel<64>, Dq64<64>::LDS_BYTES, who)) return e;
             asked64[dev] = true;
         }
     }
@@ -1530,12 +1823,14 @@ int attn_bwd_impl(const void* q, const void* k, const void* v, const void* out, 
         hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)nb), block, 0, stream, a.O, a.dO, so, sdo, delta, B, S, H);
         if (kDrop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, kDrop>), gkv, block, 2 * DKV_BUF, stream, akv);
         else hipLaunchKernelGGL(attn_bwd_dkv64_kernel<128>, gkv, block, Dkv64<128>::LDS_BYTES, stream, akv);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<128, kDrop>), gq, block, 4 * TILE, stream, aq);
+        if (kDrop) hipLaunchKernelGGL((attn_bwd_dq_kernel<128, kDrop>), gq, block, 4 * TILE, stream, aq);
+        else hipLaunchKernelGGL(attn_bwd_dq64_kernel<128>, gq, block, Dq64<128>::LDS_BYTES, stream, aq);
     } else {
         hipLaunchKernelGGL(attn_delta_kernel<64>, dim3((unsigned)nb), block, 0, stream, a.O, a.dO, so, sdo, delta, B, S, H);
         if (kDrop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, kDrop>), gkv, block, 2 * DKV_BUF, stream, akv);
         else hipLaunchKernelGGL(attn_bwd_dkv64_kernel<64>, gkv, block, Dkv64<64>::LDS_BYTES, stream, akv);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<64, kDrop>), gq, block, 4 * TILE, stream, aq);
+        if (kDrop) hipLaunchKernelGGL((attn_bwd_dq_kernel<64, kDrop>), gq, block, 4 * TILE, stream, aq);
+        else hipLaunchKernelGGL(attn_bwd_dq64_kernel<64>, gq, block, Dq64<64>::LDS_BYTES, stream, aq);
     }
     return mgen_check_launch(who);
 }

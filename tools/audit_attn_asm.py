@@ -1,6 +1,6 @@
 """Build check for the attention kernels that address accumulator registers by number (csrc/attn_impl.h): in the
 compiler's assembly output, every v_accvgpr_* instruction OUTSIDE an inline-asm statement must name a register below
-the range the kernel keeps for itself (forward: a64 and up; dK/dV with 64 keys per wave: all of them), and the kernels
+the range the kernel keeps for itself (forward: a64 and up; the backward kernels with 64 rows per wave: all of them), and the kernels
 must use no scratch.
 
     python tools/audit_attn_asm.py file.s
@@ -8,13 +8,13 @@ must use no scratch.
 import re
 import sys
 
-RESERVED_FROM = {"attn_fwd_kernel": 64, "attn_bwd_dkv64_kernel": 0}
+RESERVED_FROM = {"attn_fwd_kernel": 64, "attn_bwd_dkv64_kernel": 0, "attn_bwd_dq64_kernel": 0}
 
 
 def main(path):
     kernel, in_asm, bad, checked, first = None, False, [], 0, 0
     for n, line in enumerate(open(path), 1):
-        m = re.match(r"^(_ZN\w*?(attn_fwd_kernel|attn_bwd_dkv64_kernel)\w*):", line)
+        m = re.match(r"^(_ZN\w*?(attn_fwd_kernel|attn_bwd_dkv64_kernel|attn_bwd_dq64_kernel)\w*):", line)
         if m:
             kernel, in_asm, first = m.group(1), False, RESERVED_FROM[m.group(2)]
             checked += 1
