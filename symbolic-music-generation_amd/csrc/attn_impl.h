@@ -1063,6 +1063,43 @@ template <int HD> struct Dkv64 {
     static constexpr int LDS_BYTES = DELR + 2 * VECB;
 };
 
+// LDS reads through an LDS byte address held in a register (the workgroup's LDS base is folded into the per-lane
+// offsets once, so a read costs no address arithmetic beyond the XOR that selects its chunk)
+__device__ __forceinline__ bf16x8 ldsa_read_b128(int addr) {
+#ifdef MGEN_DBG_NOLDS
+    return bf16x8{};
+#endif
+    return *(const __attribute__((address_space(3))) bf16x8*)(unsigned)addr;
+}
+__device__ __forceinline__ f32x4 ldsa_read_f32x4(int addr) {
+    return *(const __attribute__((address_space(3))) f32x4*)(unsigned)addr;
+}
+__device__ __forceinline__ bf16x8 ldsa_col_frag(int addr_a, int addr_b) {
+#ifdef MGEN_DBG_NOLDS
+    return bf16x8{};
+#endif
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(unsigned)addr_a);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(unsigned)addr_b);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, both);
+}
+// One 64-row tile piece set of a wave (TileStream<4>: 4 pieces 16 rows apart) in ONE asm statement: M0 and the scalar
+// offset advance inside it (M0 is declared clobbered instead of being saved and restored around every load).
+__device__ __forceinline__ void tile_issue4(const TileStream<4>& t, int row0, unsigned lds_base, int wave, int extra = 0) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
+    int soff = __builtin_amdgcn_readfirstlane(row0 * t.row_bytes + extra);
+    const int step = __builtin_amdgcn_readfirstlane(16 * t.row_bytes);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_add_u32 %0, %0, %4\n\t"
+                 "buffer_load_dwordx4 %2, %3, %0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_add_u32 %0, %0, %4\n\t"
+                 "buffer_load_dwordx4 %2, %3, %0 offen lds\n\t"
+                 "s_add_u32 m0, m0, 0x1000\n\ts_add_u32 %0, %0, %4\n\t"
+                 "buffer_load_dwordx4 %2, %3, %0 offen lds"
+                 : "+s"(soff) : "s"(dst), "v"(t.voff), "s"(t.rsrc), "s"(step) : "memory", "m0", "scc");
+}
 template <int HD>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     using G = Geo<HD>;
@@ -1073,10 +1110,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     constexpr int NP = 2 * KS, NV = 4 * DB, NS = 2 * KS, NK = 4 * DB, KH = NK / 4;
     constexpr int pV = NP, pK0 = pV + NV, pS = pK0 + KH, pK1 = pS + NS, NU = pK1 + NK - KH;
     constexpr int LEAD = 4, LEADS = KH < 4 ? KH : 4;      // slots between an LDS read and its MFMA
-    // vector steps: exponentials (34 steps: multiply-add of element n, exponential of n - 1, packing of pairs)
+    // vector steps: exponentials (34 steps: multiply-add of element n, exponential of n - 1, packing of pairs). Packed
+    // fp32 instructions (v_pk_*_f32) are not used: next to MFMAs they run at a fraction of their stand-alone rate
     constexpr int NV1 = 34, W1A = NU - (pS + NS + 1), W1B = NP - 1, N1A = NV1 * W1A / (W1A + W1B);
     constexpr int NV2 = 34, W2 = NV - 2;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     asm volatile("" ::: "a255");   // the kernel allocates all accumulator registers; the compiler uses none of them
 
     const int tid = threadIdx.x, lane = tid & 63, hh = lane >> 5;
@@ -1104,11 +1142,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     const unsigned lds0 = lds_addr(smem);
 
     // per-lane LDS offsets; a ring slot's base is added and the k-step / d-block enters by XOR (see row_frag_off)
-    const int rrow = row_frag_off(ks0, lane);
-    const int ccol = col_frag_off(db0, false, lane);
+    // (LDS byte ADDRESSES: the workgroup's LDS base, a multiple of 1 KiB, is part of them)
+    const int rrow = (int)lds0 + row_frag_off(ks0, lane);
+    const int ccol = (int)lds0 + col_frag_off(db0, false, lane);
     const int aV = rrow + L::VRES + wk * TILE;
-    const int vecoff = 16 * hh + 256 * sub;
-    const int kwl = 64 * wk + (lane & 31) - 4 * hh;      // + k0: block A's key of this lane, minus the lane half's row offset
+    const int vecoff = (int)lds0 + 16 * hh + 256 * sub;
 
     for (int pass = 0; pass < npass; ++pass) {
     const int kb = pass == 0 ? bid.x : a.nqb - 1 - bid.x;
@@ -1122,8 +1160,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
         const int hrel = HD == 128 ? s / per_head : 0;
         const int qt0 = (t_first + s % per_head) * 64;
         const unsigned q3 = (unsigned)(s % 3), d2 = (unsigned)(s & 1);
-        Qs.issue(qt0, lds0 + L::QRING + q3 * TILE, wave, hrel * HD * 2);
-        dOs.issue(qt0, lds0 + L::DORING + d2 * TILE, wave, hrel * HD * 2);
+        tile_issue4(Qs, qt0, lds0 + L::QRING + q3 * TILE, wave, hrel * HD * 2);
+        tile_issue4(dOs, qt0, lds0 + L::DORING + d2 * TILE, wave, hrel * HD * 2);
         if (wave < L::HPB) Ls.issue((long)(hrel + wave) * S + qt0, lds0 + L::LSER + q3 * L::VECB + wave * 256);
         else if (wave >= 2 && wave < 2 + L::HPB)
             Ds.issue((long)(hrel + wave - 2) * S + qt0, lds0 + L::DELR + d2 * L::VECB + (wave - 2) * 256);
@@ -1140,8 +1178,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     bf16x8 kf[2][KS];
     {
         const int lp = fresh_lane();
-        load_own_rows<KS>(kf[0], a.K + (long)kvh * HD, a.sk, tok0, kw0, S, lp);
-        load_own_rows<KS>(kf[1], a.K + (long)kvh * HD, a.sk, tok0, kw0 + 32, S, lp);
+        int hk;   // (an asm copy: the pointers are formed here, not kept in registers from the kernel's start)
+        asm volatile("s_mov_b32 %0, %1" : "=s"(hk) : "s"(kvh));
+        load_own_rows<KS>(kf[0], a.K + (long)hk * HD, a.sk, tok0, kw0, S, lp);
+        load_own_rows<KS>(kf[1], a.K + (long)hk * HD, a.sk, tok0, kw0 + 32, S, lp);
     }
     static_for<4 * DB * 16>([&](auto ic) { acc_write<decltype(ic)::value>(0.f); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1157,7 +1197,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     float nlg[4];
     int thrA[2], thrS = 0;               // causal / sequence-end thresholds of the unit whose exponentials are in progress
     thrA[0] = thrA[1] = 0;
-    const float neg_big = NEG_BIG;
     bf16x8 fD[KS], fVA[KS], fVB[KS], fDT[2 * DB], fQn[KS], fQT[2 * DB];
 
     // element e of a unit, in the order both vector stages walk: row group g4 = e / 8, block (e / 4) % 2,
@@ -1166,15 +1205,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
 
     auto read_lse = [&](auto gc, int lseb, int un) {
         constexpr int g4 = decltype(gc)::value;
-        lv[g4] = *reinterpret_cast<const f32x4*>(smem + lseb + vecoff + 128 * un + 32 * g4);
+        lv[g4] = ldsa_read_f32x4(lseb + vecoff + 128 * un + 32 * g4);
     };
     auto read_delta = [&](auto gc, int delb, int u) {
         constexpr int g4 = decltype(gc)::value;
-        dl[g4] = *reinterpret_cast<const f32x4*>(smem + delb + vecoff + 128 * u + 32 * g4);
+        dl[g4] = ldsa_read_f32x4(delb + vecoff + 128 * u + 32 * g4);
     };
     // exponential stage, step n in [0, NV1): p = exp2(s * scale * log2 e - lse * log2 e)
-    auto v1_step = [&](auto nc, auto maskc, int lseb, int un) {
+    auto v1_step = [&](auto nc, auto maskc, int lseb, int un) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
+#ifdef MGEN_DBG_NOVALU
+        return;
+#endif
         constexpr bool MASKED = decltype(maskc)::value;
         if constexpr (n < 32) {
             constexpr int e = n, g4 = e >> 3, blk = (e >> 2) & 1, i = e & 3, r = 4 * g4 + i;
@@ -1183,9 +1225,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
             float x = a_fma(sc[blk][r], sl2, nlg[i]);
             if constexpr (MASKED) {   // hidden when c_r < thrA (key after query) or c_r >= thrS (query past the end)
                 constexpr int c = (r & 3) + 8 * (r >> 2);
-                asm volatile("v_cmp_lt_i32_e32 vcc, %2, %3\n\tv_cndmask_b32_e32 %0, %0, %1, vcc\n\t"
+                float big;   // -1e30
+                asm volatile("v_mov_b32 %1, 0xf149f2ca\n\t"
+                             "v_cmp_lt_i32_e32 vcc, %2, %3\n\tv_cndmask_b32_e32 %0, %0, %1, vcc\n\t"
                              "v_cmp_ge_i32_e32 vcc, %2, %4\n\tv_cndmask_b32_e32 %0, %0, %1, vcc"
-                             : "+v"(x) : "v"(neg_big), "n"(c), "v"(thrA[blk]), "v"(thrS) : "vcc");
+                             : "+v"(x), "=&v"(big) : "n"(c), "v"(thrA[blk]), "v"(thrS) : "vcc");
             }
             xs[e] = x;
         }
@@ -1196,8 +1240,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
         }
     };
     // dS stage, step n in [0, NV2): dS = P (dP - delta)
-    auto v2_step = [&](auto nc, int delb, int u) {
+    auto v2_step = [&](auto nc, int delb, int u) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
+#ifdef MGEN_DBG_NOVALU
+        return;
+#endif
         if constexpr (n < 32) {
             constexpr int e = n, g4 = e >> 3, blk = (e >> 2) & 1, i = e & 3, r = 4 * g4 + i;
             if constexpr ((e & 7) == 0 && g4 + 1 < 4) read_delta(std::integral_constant<int, g4 + 1>{}, delb, u);
@@ -1210,27 +1257,44 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
         const u32x4 v = {w[4 * f], w[4 * f + 1], w[4 * f + 2], w[4 * f + 3]};
         return __builtin_bit_cast(bf16x8, v);
     };
-    auto set_thr = [&](int qt0, int un) {
-        thrA[0] = k0 + kwl - qt0 - 32 * un;
+    auto set_thr = [&](int qt0, int un) __attribute__((always_inline)) {   // (rare: the lane's part is computed here)
+        const int lt = fresh_lane(), h4 = 4 * (lt >> 5);
+        thrA[0] = kw0 + (lt & 31) - h4 - qt0 - 32 * un;   // block A's key of this lane, minus the lane half's row offset
         thrA[1] = thrA[0] + 32;
-        thrS = S - qt0 - 32 * un - 4 * hh;
+        thrS = S - qt0 - 32 * un - h4;
     };
     // fragments the P group of a unit needs before its first slots (read at the end of the unit before)
     auto read_p_head = [&](auto ic, int aD, int u) {
         constexpr int i = decltype(ic)::value;   // 0: dO[0], V_A[0]; 1: V_B[0]; 2: dO[1], V_A[1]
-        if constexpr (i == 0) { fD[0] = lds_read_b128(smem, aD + 8192 * u); fVA[0] = lds_read_b128(smem, aV); }
-        if constexpr (i == 1) fVB[0] = lds_read_b128(smem, aV + 8192);
+        if constexpr (i == 0) { fD[0] = ldsa_read_b128(aD + 8192 * u); fVA[0] = ldsa_read_b128(aV); }
+        if constexpr (i == 1) fVB[0] = ldsa_read_b128(aV + 8192);
         if constexpr (i == 2) {
-            fD[1] = lds_read_b128(smem, (aD ^ 32) + 8192 * u);
-            fVA[1] = lds_read_b128(smem, aV ^ 32);
+            fD[1] = ldsa_read_b128((aD ^ 32) + 8192 * u);
+            fVA[1] = ldsa_read_b128(aV ^ 32);
         }
     };
 
     int s = 0;   // step = 64-query tile of one query head
+#ifdef MGEN_DKV_STAMPS   // diagnostic build: cycles spent waiting at / issuing loads behind the tile barrier
+    unsigned long long st_wait = 0, st_issue = 0, st_begin = __builtin_amdgcn_s_memtime();
+#endif
     auto sync = [&]() __attribute__((always_inline)) {
+#ifdef MGEN_DKV_STAMPS
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef MGEN_DKV_STAMPS
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef MGEN_DBG_NODMA
         if (s + 2 < nsteps) issue_step(s + 2);
+#endif
+#ifdef MGEN_DKV_STAMPS
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        st_wait += t1 - t0;
+        st_issue += t2 - t1;
+#endif
     };
 
     // One unit. U: which half of the tile; M_CUR / M_NEXT: the unit's / the next unit's exponentials take the masks;
@@ -1264,24 +1328,24 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
             static_for<KS>([&](auto kc) {
                 constexpr int ks = decltype(kc)::value;
                 if constexpr (ks >= 2 && g == 2 * ks - 3) {
-                    fD[ks] = lds_read_b128(smem, (aD ^ (32 * ks)) + 8192 * U);
-                    fVA[ks] = lds_read_b128(smem, aV ^ (32 * ks));
+                    fD[ks] = ldsa_read_b128((aD ^ (32 * ks)) + 8192 * U);
+                    fVA[ks] = ldsa_read_b128(aV ^ (32 * ks));
                 }
-                if constexpr (ks >= 1 && g == 2 * ks - 2) fVB[ks] = lds_read_b128(smem, (aV ^ (32 * ks)) + 8192);
+                if constexpr (ks >= 1 && g == 2 * ks - 2) fVB[ks] = ldsa_read_b128((aV ^ (32 * ks)) + 8192);
                 if constexpr (HAS_NEXT && g == pS + 2 * ks - LEADS)
-                    fQn[ks] = lds_read_b128(smem, (aQn ^ (32 * ks)) + 8192 * UN);
+                    fQn[ks] = ldsa_read_b128((aQn ^ (32 * ks)) + 8192 * UN);
             });
             static_for<2 * DB>([&](auto ic) {
                 constexpr int i = decltype(ic)::value, db = i >> 1, half = i & 1;
                 constexpr int im = 8192 * U + 4096 * half;
                 if constexpr (g == pV + 2 * i - LEAD) {
                     const int x = cD ^ (64 * db);
-                    fDT[i] = col_frag(smem, x + im, (x ^ 32) + 2048 + im);
+                    fDT[i] = ldsa_col_frag(x + im, (x ^ 32) + 2048 + im);
                 }
                 constexpr int ck = 2 * i < KH ? pK0 + 2 * i : pK1 + 2 * i - KH;
                 if constexpr (g == ck - LEAD) {
                     const int x = cQ ^ (64 * db);
-                    fQT[i] = col_frag(smem, x + im, (x ^ 32) + 2048 + im);
+                    fQT[i] = ldsa_col_frag(x + im, (x ^ 32) + 2048 + im);
                 }
             });
             if constexpr (HAS_NEXT && g >= NU - 3) read_p_head(std::integral_constant<int, g - (NU - 3)>{}, aDn, UN);
@@ -1319,7 +1383,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
         const int aQ = rrow + qb;
         static_for<KS>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
-            const bf16x8 f = lds_read_b128(smem, aQ ^ (32 * ks));
+            const bf16x8 f = ldsa_read_b128(aQ ^ (32 * ks));
             if constexpr (ks == 0) { mfma_vv0(sc[0], f, kf[0][ks]); mfma_vv0(sc[1], f, kf[1][ks]); }
             else { mfma_vv(sc[0], f, kf[0][ks]); mfma_vv(sc[1], f, kf[1][ks]); }
         });
@@ -1388,6 +1452,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     char* obuf = smem + L::DORING + wave * 8192;
     const int le = fresh_lane(), he = le >> 5;
+    int hk;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(hk) : "s"(kvh));
     static_for<4>([&](auto oc) {
         constexpr int which = decltype(oc)::value >> 1, blk = decltype(oc)::value & 1;   // 0: dV, 1: dK
         const float mul = which ? a.scale : 1.f;
@@ -1408,10 +1474,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
         for (int i = 0; i < 32 / RPI; ++i) {
             const int row = i * RPI + r0, key = kw0 + 32 * blk + row;
             const bf16x8 v = lds_read_b128(obuf, img256_off(row, 4 * db0 + c));
-            if (key < S) *reinterpret_cast<bf16x8*>(dst + (tok0 + key) * ld + (long)kvh * HD + 8 * c) = v;
+            if (key < S) *reinterpret_cast<bf16x8*>(dst + (tok0 + key) * ld + (long)hk * HD + 8 * c) = v;
         }
     });
     __syncthreads();   // the rings and the V image are free for the next pass
+#ifdef MGEN_DKV_STAMPS
+    if (le == 0 && kw0 < S) {
+        unsigned* d = reinterpret_cast<unsigned*>(a.dV + (tok0 + kw0) * a.sdv + (long)kvh * HD);
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        d[0] = (unsigned)(t3 - st_begin); d[1] = (unsigned)st_wait; d[2] = (unsigned)st_issue; d[3] = (unsigned)nsteps;
+        d[4] = (unsigned)skipn; d[5] = (unsigned)pass;
+    }
+#endif
     }   // pass
 }
 
@@ -1521,6 +1595,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(AttnArgs a) {
     auto widx = [](int e) constexpr { return (((e >> 3) & 1) * 2 + (e >> 4)) * 4 + ((e & 7) >> 1); };
     auto v1_step = [&](auto nc, auto maskc) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
+#ifdef MGEN_DBG_NOVALU
+        return;
+#endif
         if constexpr (n < 32) {
             constexpr int e = n, blk = (e >> 3) & 1, r = 8 * (e >> 4) + (e & 7);
             float x = a_fma(sc[blk][r], sl2, nl[blk]);
@@ -1535,6 +1612,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(AttnArgs a) {
     };
     auto v2_step = [&](auto nc) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
+#ifdef MGEN_DBG_NOVALU
+        return;
+#endif
         if constexpr (n < 32) {
             constexpr int e = n, blk = (e >> 3) & 1, r = 8 * (e >> 4) + (e & 7);
             ts[e] = a_sub(dp[blk][r], delta[blk]);
