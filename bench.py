@@ -65,12 +65,22 @@ def cpu_baseline(cfg, S, seconds_budget=25.0):
                       f"best of {len(times)} runs, {best:.2f} s/step"}
 
 
+def pmc_decode_traffic(streams, prompt_len):
+    """HBM bytes per decode step from the committed counter passes (profiles/r02_pmc_traffic.json, section "decode":
+    256 streams, contexts 1792..1808): every kernel of a decode step, fetch + write. None for any other shape."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if (streams, prompt_len) != (256, 1792) or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh).get("decode_step_hbm_bytes")
+
+
 def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
-    """Batched sampling (BASELINE.json configs[3] shape: 256 streams, contexts up to 4096): `streams` concurrent
-    KV-cache decode streams on a random prompt of `prompt_len` tokens, temperature 0.97, top-p 0.95, no top-k, EOS
-    disabled, Philox noise seed 1234. The decode rate is (time of prefill + N steps) - (time of prefill + 1 step) over
+    """Batched sampling (BASELINE.json configs[3]: 256 streams, contexts up to 4096): `streams` concurrent KV-cache
+    decode streams on a random prompt of `prompt_len` tokens, temperature 0.97, top-p 0.95, no top-k, EOS disabled,
+    Philox noise seed 1234. The decode rate is (time of prefill + N steps) - (time of prefill + 1 step) over
     N - 1 steps; algorithmic bytes per step = bf16 weights + the [streams, V] bf16 logits + the KV cache of the
-    context. Reported per GPU."""
+    context, summed over the run's growing contexts. Reported per GPU, with a roofline block (bound: hbm)."""
     g = torch.Generator().manual_seed(99)
     prompt = torch.randint(3, 30000, (streams, prompt_len), generator=g).to(dev)
     kw = dict(do_sample=True, temperature=0.97, top_k=0, top_p=0.95, seed=1234)
@@ -92,11 +102,17 @@ def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
     weights = 2 * (sum(p.numel() for p in model.parameters()))
     ctx_sum = sum(range(prompt_len + 1, prompt_len + steps + 1))  # keys read by the decode steps
     bytes_total = steps * (weights + streams * cfg.vocab_size * 2) + streams * ctx_sum * kv_tok
+    gbs = bytes_total / dt / 1e9
     return {"streams": streams, "prompt_len": prompt_len, "new_tokens": new_tokens,
             "tokens_per_s_per_gpu": round(streams * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "prefill_tokens_per_s": round(streams * prompt_len / t1, 1),
-            "algorithmic_GBps": round(bytes_total / dt / 1e9, 1),
-            "hbm_frac": round(bytes_total / dt / 1e9 / PEAK_HBM_GBS, 4),
+            "algorithmic_GBps": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(gbs / PEAK_HBM_GBS, 4),
+                         "algorithmic_bytes": round(bytes_total / steps),
+                         "traffic": pmc_decode_traffic(streams, prompt_len),
+                         "traffic_unit": "HBM bytes per decode step, all kernels of the step (PMC FETCH_SIZE + WRITE_SIZE, "
+                                         "profiles/r02_pmc_traffic.json); algorithmic_bytes = run average per step"},
             "sampling": "T=0.97 top_p=0.95 top_k=off philox(seed 1234)", "out_shape": list(out.shape)}
 
 
@@ -104,6 +120,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--decode-streams", type=int, default=256)
     ap.add_argument("--decode-tokens", type=int, default=256, help="0 disables the decode measurement")
+    ap.add_argument("--decode-full", type=int, default=4096,
+                    help="total length of the configs[3] decode run (one-token prompt, decode-full - 1 new tokens)")
     ap.add_argument("--decode-prompt", type=int, default=1792,
                     help="prompt length of the decode measurement (contexts run from here to +decode-tokens)")
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,17 +215,17 @@ def main():
         ms = sum(r[1].elapsed_time(r[2]) for r in recs)
         achieved = fl / (ms * 1e-3) / 1e12
         # HBM traffic per launch of this kernel cannot be counted from inside the process: it comes from the committed
-        # PMC passes of this same command (profiles/r01_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs,
+        # PMC passes of this same command (profiles/r02_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs,
         # FETCH doubled per the gfx950 note), valid for the default workload only
         traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
         if (B, S) == (32, 2048) and args.model == "default" and os.path.exists(pmc):
             with open(pmc) as fh:
                 traffic = json.load(fh).get("gemm_fwd_bf16_avg_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "gemm_kernel<TA=0,TB=0,OUT_BF16> (QKV, gate-up, lm_head forward)",
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json); algorithmic: "
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r02_pmc_traffic.json); algorithmic: "
                                     "2*(M*K + N*K + M*N) bytes",
                     "algorithmic_bytes_per_launch": round(sum(r[3] for r in recs) / len(recs)),
                     "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 4),
@@ -229,12 +247,22 @@ def main():
             "mfma_frac_whole_step": round(tokens_per_s / world * ftok / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": roofline,
         }
+        if world > 1:
+            log = list(trainer.reducer.bucket_log)
+            out["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())
+                           if dist.get_backend() == "nccl" else None,
+                           "collective": "all_reduce(AVG)" if trainer.reducer._native_avg else "all_reduce(SUM) / N",
+                           "buckets": [{"bytes": b, "dtype": d} for b, d in log],
+                           "bytes_per_step": sum(b for b, _ in log)}
         if world == 1 and args.decode_tokens > 0:
             del trainer, batch
             model.zero_grad()
             torch.cuda.empty_cache()
-            out["decode"] = bench_decode(model, cfg, args.decode_streams, args.decode_prompt, args.decode_tokens, dev)
-            out["decode_short_context"] = bench_decode(model, cfg, args.decode_streams, 1, args.decode_tokens, dev)
+            # BASELINE.json configs[3] as written: 256 streams from a one-token (BOS) prompt to 4096 tokens
+            out["decode"] = bench_decode(model, cfg, args.decode_streams, 1, args.decode_full - 1, dev)
+            out["decode_long_context"] = bench_decode(model, cfg, args.decode_streams, args.decode_prompt,
+                                                      args.decode_tokens, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, S)
         print(json.dumps(out))

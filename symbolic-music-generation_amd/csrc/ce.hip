@@ -139,83 +139,134 @@ __global__ __launch_bounds__(256) void ce_kernel(LT* __restrict__ logits, const 
 }
 
 // bf16 rows of up to NT * 8 * NV logits with the whole row held in registers (16 bytes x NV per thread, NT
-// threads): the logits are read from memory once and the gradient written once, instead of read twice. Same
-// arithmetic as ce_kernel; only the order of the partial sums differs.
+// threads): the logits are read from memory once and the gradient written once, instead of read twice.
+// One block per CU holds a row, so the vector work of a row is not hidden behind another row's loads: it is kept
+// short. Three passes over the registers: maximum (one v_max3 per pair), sum of exp2(x log2e - M), and the gradient
+// exp2(x log2e - M - log2(sum) + log2(g)) with the label's element and the columns past V patched afterwards.
+__device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
 template <int NT, int NV, bool WRITE_GRAD>
 __global__ __launch_bounds__(NT) void ce_row_kernel(bf16* __restrict__ logits, const long* __restrict__ labels,
-                                                      long tok0, int V, long ld, int S, long ignore_index,
+                                                      long tok0, long rows, int V, long ld, int S, long ignore_index,
                                                       const float* __restrict__ inv_count, float grad_scale,
                                                       float* __restrict__ row_loss, float* __restrict__ lse_out) {
     __shared__ float red[2][NT / 64];
     const int tid = threadIdx.x, wave = tid >> 6;
-    const long r = blockIdx.x;
-    const long t = tok0 + r;
-    const int s = (int)(t % S);
-    long label = ignore_index;
-    if (s + 1 < S) label = labels[t + 1];
-    const bool valid = label != ignore_index && label >= 0 && label < V;
-    bf16* row = logits + r * ld;
     const int nvec = (V + 7) / 8;
+    const int vlast = V >> 3, vrem = V & 7;   // vector vlast holds the first column past V (when V is no multiple of 8)
 
-    bf16x8 v[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
+    // A block walks rows blockIdx.x, + gridDim.x, ...; the next row's vectors are requested into the registers the
+    // current row's gradient has just left, so a CU's loads travel while it computes and stores.
+    u32x4 v[NV];
+    auto load_vec = [&](const bf16* row, int j) {
         const int i = tid + j * NT;
-        if (i < nvec) v[j] = *reinterpret_cast<const bf16x8*>(row + (long)i * 8);
+        if (i < nvec) v[j] = *reinterpret_cast<const u32x4*>(row + (long)i * 8);
+        else v[j] = u32x4{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};   // -inf: no weight in max or sum
+    };
+    long r = blockIdx.x;
+    if (r < rows) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) load_vec(logits + r * ld, j);
     }
-    float m = -1.0e30f, sum = 0.f;
+    for (; r < rows; r += gridDim.x) {
+        const long t = tok0 + r;
+        const int s = (int)(t % S);
+        long label = ignore_index;
+        if (s + 1 < S) label = labels[t + 1];
+        const bool valid = label != ignore_index && label >= 0 && label < V;
+        bf16* row = logits + r * ld;
+        const long rn = r + gridDim.x;
+        const bool has_next = rn < rows;
+        const bf16* row_next = logits + (has_next ? rn : r) * ld;
+        if (vrem) {   // columns past V inside the last vector
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = tid + j * NT;
-        if (i < nvec) {
-            float x[8];
-            float mx = m;
+            for (int j = 0; j < NV; ++j)
+                if (tid + j * NT == vlast) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                x[e] = (i * 8 + e < V) ? (float)v[j][e] * LOG2E : -1.0e30f;
-                mx = fmaxf(mx, x[e]);
-            }
-            float acc = sum * __builtin_amdgcn_exp2f(m - mx);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += __builtin_amdgcn_exp2f(x[e] - mx);
-            sum = acc;
-            m = mx;
+                    for (int e = 0; e < 8; ++e)
+                        if (e >= vrem) v[j][e >> 1] = (e & 1) ? ((v[j][e >> 1] & 0xffffu) | 0xff800000u)
+                                                              : ((v[j][e >> 1] & 0xffff0000u) | 0xff80u);
+                }
         }
-    }
-    const float wm = wave_max(m);
-    if ((tid & 63) == 0) red[0][wave] = wm;
-    __syncthreads();
-    float M = red[0][0];
+        float m = -3.0e38f;
 #pragma unroll
-    for (int w = 1; w < NT / 64; ++w) M = fmaxf(M, red[0][w]);
-    const float ws = wave_sum(sum * __builtin_amdgcn_exp2f(m - M));
-    if ((tid & 63) == 0) red[1][wave] = ws;
-    __syncthreads();
-    sum = 0.f;
+        for (int j = 0; j < NV; ++j)
 #pragma unroll
-    for (int w = 0; w < NT / 64; ++w) sum += red[1][w];
-    const float lse = (M + __log2f(sum)) * LN2;
-    if (tid == 0) {
-        if (lse_out) lse_out[t] = lse;
-        row_loss[t] = valid ? (lse - (float)row[label]) : 0.f;
-    }
-    if (!WRITE_GRAD) return;
-    __syncthreads();  // row[label] is read above before anyone overwrites the row
-    const float g = valid ? grad_scale * (*inv_count) : 0.f;
-    const float inv_sum = 1.f / sum;
+            for (int w = 0; w < 4; ++w) m = __builtin_fmaxf(m, __builtin_fmaxf(bf_lo(v[j][w]), bf_hi(v[j][w])));
+        const float wm = wave_max(m);
+        __syncthreads();   // the previous row's readers of red[] are done
+        if ((tid & 63) == 0) red[0][wave] = wm;
+        __syncthreads();
+        // (the row's registers pass through an empty asm between the passes: the unpacked values of one pass are not
+        // kept for the next, which would need twice the register file)
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = tid + j * NT;
-        if (i < nvec) {
-            bf16x8 o;
+        for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(v[j]));
+        float M = red[0][0];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int idx = i * 8 + e;
-                float p = __builtin_amdgcn_exp2f((float)v[j][e] * LOG2E - M) * inv_sum;
-                if (idx == label) p -= 1.f;
-                o[e] = (bf16)(idx < V ? p * g : 0.f);
+        for (int w = 1; w < NT / 64; ++w) M = fmaxf(M, red[0][w]);
+        M *= LOG2E;   // the row maximum in the exponent's units (finite: every row has V >= 1 real columns)
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                sum += __builtin_amdgcn_exp2f(__builtin_fmaf(bf_lo(v[j][w]), LOG2E, -M));
+                sum += __builtin_amdgcn_exp2f(__builtin_fmaf(bf_hi(v[j][w]), LOG2E, -M));
             }
-            *reinterpret_cast<bf16x8*>(row + (long)i * 8) = o;
+        const float ws = wave_sum(sum);
+        if ((tid & 63) == 0) red[1][wave] = ws;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(v[j]));
+        sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) sum += red[1][w];
+        const float l2s = __log2f(sum);
+        const float lse = (M + l2s) * LN2;
+        if (tid == 0) {
+            if (lse_out) lse_out[t] = lse;
+            row_loss[t] = valid ? (lse - (float)row[label]) : 0.f;
+        }
+        if (!WRITE_GRAD) {
+            if (has_next) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) load_vec(row_next, j);
+            }
+            continue;
+        }
+        __syncthreads();  // row[label] is read above before anyone overwrites the row
+        const float g = valid ? grad_scale * (*inv_count) : 0.f;
+        // p g = exp2(x log2e - M - log2(sum) + log2(g)); g = 0 (ignored row) gives exp2(-inf) = 0
+        const float shift = -M - l2s + __log2f(g);
+        const int lvec = valid ? (int)(label >> 3) : -1, le = (int)(label & 7);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + j * NT;
+            if (i < nvec) {
+                u32x4 o;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(bf_lo(v[j][w]), LOG2E, shift));
+                    const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(bf_hi(v[j][w]), LOG2E, shift));
+                    const bf16x2 pk = {(bf16)p0, (bf16)p1};
+                    o[w] = __builtin_bit_cast(unsigned, pk);
+                }
+                if (i == lvec) {   // the label's column: (p - 1) g, from the same p the other columns are scaled from
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        if (w == (le >> 1)) {
+                            const float x = (le & 1) ? bf_hi(v[j][w]) : bf_lo(v[j][w]);
+                            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x, LOG2E, -M - l2s));
+                            const bf16 q = (bf16)((p - 1.f) * g);
+                            const unsigned qb = (unsigned)__builtin_bit_cast(unsigned short, q);
+                            o[w] = (le & 1) ? ((o[w] & 0xffffu) | (qb << 16)) : ((o[w] & 0xffff0000u) | qb);
+                        }
+                }
+                // (columns past V inside the last vector were set to -inf: their gradient is exp2(-inf) = 0)
+                *reinterpret_cast<u32x4*>(row + (long)i * 8) = o;
+            }
+            if (has_next) load_vec(row_next, j);
         }
     }
 }
@@ -267,9 +318,16 @@ extern "C" int mgen_ce_fwd_bwd(void* logits, const long* labels, long tok0, long
     static const int row_env = [] { const char* e = getenv("MGEN_CE_ROW"); return e ? atoi(e) : 1; }();
     if (is_bf16 && row_env && nvec > 2048 && nvec <= 512 * 38) {
         // long bf16 rows (the 151,936-entry vocabulary): one 512-thread block keeps the row in registers
+        // one resident block per CU (the row fills the register file), each walking rows grid-stride
+        static const int ncu = [] {
+            hipDeviceProp_t pr; int d = 0;
+            if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&pr, d) != hipSuccess) return 256;
+            return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        }();
+        const dim3 rgrid((unsigned)(rows < ncu ? rows : ncu));
 #define CE_ROW(NV_, WG)                                                                                          \
-    hipLaunchKernelGGL((ce_row_kernel<512, NV_, WG>), grid, dim3(512), 0, stream, (bf16*)logits, labels, tok0, V, ld, S, \
-                       ignore_index, inv_count, grad_scale, row_loss, lse_out)
+    hipLaunchKernelGGL((ce_row_kernel<512, NV_, WG>), rgrid, dim3(512), 0, stream, (bf16*)logits, labels, tok0, rows, V, \
+                       ld, S, ignore_index, inv_count, grad_scale, row_loss, lse_out)
         if (nvec <= 512 * 16) { if (write_grad) CE_ROW(16, true); else CE_ROW(16, false); }
         else { if (write_grad) CE_ROW(38, true); else CE_ROW(38, false); }
 #undef CE_ROW

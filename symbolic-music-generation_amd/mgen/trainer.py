@@ -29,6 +29,7 @@ class GradReducer:
         self.min_bucket = min_bucket_elems
         self._pending = []
         self._open: Optional[list] = None  # [start, end) of the bucket being grown (ranges arrive high -> low)
+        self.bucket_log = []   # (bytes, dtype) of every collective of the last step, in issue order
         self._ranges = {tag: (s, e) for tag, s, e in model.grad_ranges()}
         # RCCL averages in the collective; gloo (CPU rehearsal of the same logic) has no AVG: sum, then divide
         self._native_avg = self.world > 1 and dist.get_backend(group) == "nccl"
@@ -42,6 +43,7 @@ class GradReducer:
         s, e = self._open
         self._open = None
         buf = self.model.flat_grad[s:e]
+        self.bucket_log.append((buf.numel() * buf.element_size(), str(buf.dtype).replace("torch.", "")))
         self._pending.append((self._start(buf), buf))
 
     def _start(self, buf):
@@ -77,6 +79,7 @@ class GradReducer:
                                "build the Trainer after them")
         if self._lora is not None and self.world > 1:
             buf = self._lora.flat_grad
+            self.bucket_log.append((buf.numel() * buf.element_size(), str(buf.dtype).replace("torch.", "")))
             self._pending.append((self._start(buf), buf))
         self._flush()
         for w, buf in self._pending:
@@ -101,6 +104,7 @@ class Trainer:
 
     def training_step(self, batch):
         self.model.train()
+        self.reducer.bucket_log.clear()
         self.opt.zero_grad()
         loss = self.model(**batch).loss
         loss.backward()

@@ -1,11 +1,12 @@
-"""Turn two rocprofv3 counter passes of `bench.py --steps 1 --warmup 0 --decode-tokens 0 --no-cpu-baseline`
-(one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE, each --output-format csv) into profiles/rNN_pmc_traffic.json:
-HBM-side bytes per launch for every MFMA / attention / cross-entropy kernel, grouped by kernel name and grid size.
+"""HBM traffic per kernel from rocprofv3 counter passes.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+    python tools/pmc_traffic.py <out.json> <label>=<fetch.csv>,<write.csv>,<kernel_trace.csv> [<label>=...]
 
-FETCH_SIZE is reported in KiB and tallies 16-byte-per-lane streaming reads at half their size on gfx950, so it is
-doubled; WRITE_SIZE (KiB) is taken as it is.
+For each label (e.g. train, decode): one pass with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE and one
+--kernel-trace pass of the same command (all --output-format csv). Per kernel name and grid size the output holds
+the launches seen, average HBM-side bytes fetched and written per launch, the average duration and the resulting
+GB/s. FETCH_SIZE is reported in KiB and tallies 16-byte-per-lane streaming reads at half their size on gfx950, so it is
+doubled; WRITE_SIZE (KiB) is taken as it is. Kernels of the library only (names from the anonymous namespace).
 """
 import collections
 import csv
@@ -13,43 +14,100 @@ import json
 import sys
 
 
-def per_kernel(path, counter):
+def short(name):
+    name = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+    if name.startswith("_ZN12_GLOBAL__N_1"):
+        # a mangled name rocprofv3 left alone: keep the identifier part
+        rest = name[len("_ZN12_GLOBAL__N_1"):]
+        n = int("".join(c for c in rest[:3] if c.isdigit()))
+        rest = rest[len(str(n)):]
+        return rest[:n] + "<" + rest[n:n + 40] + ">"
+    cut = name.find("(")
+    return name[:cut] if cut > 0 else name[:100]
+
+
+def ours(name):
+    return "anonymous namespace" in name or "_GLOBAL__N_1" in name
+
+
+def counters(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
-            continue
-        name = r["Kernel_Name"]
-        if not any(k in name for k in ("gemm_kernel", "attn_", "ce_kernel", "ce_row_kernel")):
+        if r["Counter_Name"] != counter or not ours(r["Kernel_Name"]):
             continue
         wgs = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
-        acc[(name, wgs)].append(float(r["Counter_Value"]))
+        acc[(short(r["Kernel_Name"]), wgs)].append(float(r["Counter_Value"]))
     return acc
 
 
-def main(fetch_csv, write_csv, out):
-    f = per_kernel(fetch_csv, "FETCH_SIZE")
-    w = per_kernel(write_csv, "WRITE_SIZE")
-    kernels = []
-    fwd_bytes, fwd_n = 0.0, 0
+def durations(path):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if not ours(r["Kernel_Name"]):
+            continue
+        wgs = (int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])) // max(
+            1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"]))
+        acc[(short(r["Kernel_Name"]), wgs)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return acc
+
+
+def decode_step_launches(path):
+    """(kernel, workgroups) -> launches per decode step, counted over the launches after the last prefill attention
+    kernel, from the first token-embedding launch on (a decode step starts with one)."""
+    rows = [r for r in csv.DictReader(open(path)) if ours(r["Kernel_Name"])]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    pre = [i for i, r in enumerate(rows) if "attn_fwd_kernel" in r["Kernel_Name"]]
+    if not pre:
+        return {}
+    dec = rows[pre[-1] + 1:]
+    first = next((i for i, r in enumerate(dec) if "embedding_fwd" in r["Kernel_Name"]), None)
+    if first is None:
+        return {}
+    dec = dec[first:]
+    steps = sum(1 for r in dec if "embedding_fwd" in r["Kernel_Name"])
+    cnt = collections.Counter()
+    for r in dec:
+        wgs = (int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])) // max(
+            1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"]))
+        cnt[(short(r["Kernel_Name"]), wgs)] += 1
+    return {k: v / steps for k, v in cnt.items()}
+
+
+def section(fetch_csv, write_csv, trace_csv, decode=False):
+    f, w, d = counters(fetch_csv, "FETCH_SIZE"), counters(write_csv, "WRITE_SIZE"), durations(trace_csv)
+    per_step = decode_step_launches(trace_csv) if decode else {}
+    rows = []
     for key in sorted(f):
-        name, wgs = key
         fb = sum(f[key]) / len(f[key]) * 1024 * 2
-        wb = sum(w[key]) / len(w[key]) * 1024 if key in w else None
-        kernels.append({"kernel": name[:120], "workgroups": wgs, "launches_seen": len(f[key]),
-                        "fetch_bytes": round(fb), "write_bytes": None if wb is None else round(wb)})
-        if "gemm_kernel<false, false, 0" in name and wb is not None:   # x @ W^T, bf16 out: QKV, gate-up, lm_head fwd
-            fwd_bytes += (fb + wb) * len(f[key])
-            fwd_n += len(f[key])
-    doc = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 1 "
-                      "--warmup 0 --decode-tokens 0 --no-cpu-baseline",
-           "units": "bytes per launch; FETCH_SIZE (KiB) x 1024 x 2 (gfx950: 16 B/lane streaming reads are tallied at "
-                    "half), WRITE_SIZE (KiB) x 1024",
-           "kernels": kernels,
-           "gemm_fwd_bf16_avg_bytes_per_launch": round(fwd_bytes / fwd_n) if fwd_n else None,
-           "gemm_fwd_bf16_launches": fwd_n}
+        wb = sum(w[key]) / len(w[key]) * 1024 if key in w else 0.0
+        us = sum(d[key]) / len(d[key]) / 1e3 if key in d else None
+        rows.append({"kernel": key[0], "workgroups": key[1], "launches_seen": len(f[key]), "fetch_bytes": round(fb),
+                     "write_bytes": round(wb), "avg_us": None if us is None else round(us, 2),
+                     "GBps": None if not us else round((fb + wb) / us / 1e3, 1)})
+        if key in per_step:
+            rows[-1]["launches_per_decode_step"] = round(per_step[key], 2)
+    return rows
+
+
+def main(out, specs):
+    doc = {"units": "bytes per launch; FETCH_SIZE (KiB) x 1024 x 2 (gfx950: 16 B/lane streaming reads are tallied at half), "
+                    "WRITE_SIZE (KiB) x 1024; avg_us from a --kernel-trace pass of the same command; GBps = (fetch + write) / avg_us",
+           "passes": "separate rocprofv3 runs per counter (--pmc FETCH_SIZE, --pmc WRITE_SIZE) and for the kernel trace"}
+    for spec in specs:
+        label, files = spec.split("=")
+        doc[label] = section(*files.split(","), decode=label.startswith("decode"))
+        if label.startswith("decode"):
+            doc[label + "_step_hbm_bytes"] = round(sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches_per_decode_step"]
+                                                       for r in doc[label] if "launches_per_decode_step" in r))
+    fwd = [r for r in doc.get("train", []) if r["kernel"].startswith("gemm_kernel<false, false, 0")]
+    if fwd:   # x @ W^T, bf16 out: QKV, gate-up, lm_head forward: the kernel bench.py's roofline block times
+        n = sum(r["launches_seen"] for r in fwd)
+        doc["gemm_fwd_bf16_avg_bytes_per_launch"] = round(
+            sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches_seen"] for r in fwd) / n)
+        doc["gemm_fwd_bf16_launches"] = n
     json.dump(doc, open(out, "w"), indent=1)
-    print(out, "kernels", len(kernels), "fwd launches", fwd_n, "avg bytes", doc["gemm_fwd_bf16_avg_bytes_per_launch"])
+    print(out, {k: len(v) for k, v in doc.items() if isinstance(v, list)})
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(sys.argv[1], sys.argv[2:])
