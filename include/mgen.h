@@ -165,6 +165,12 @@ int mgen_dropout_resid(const void* y, const float* resid, float* out, long n, fl
  * TF models/qwen3/modeling_qwen3.py:81-83. round_silu=1 rounds silu(gate) to bf16 first (autocast behaviour). */
 int mgen_swiglu_fwd(const void* gu, void* act, long T, int I, int round_silu, mgen_stream_t stream);
 int mgen_swiglu_bwd(const void* gu, const void* dact, void* dgu, long T, int I, mgen_stream_t stream);
+/* The gate/up projection and the gate in one launch: gu[M][2I] = x[M][K] * w[2I][K]^T (w = gate rows, then up rows) and
+ * act[M][I] = silu(gate) * up from the product's epilogue, same rounding as mgen_swiglu_fwd(round_silu = 1) on the stored
+ * gu — gate_proj, up_proj and act_fn of Qwen3MLP.forward, TF models/qwen3/modeling_qwen3.py:81-83. K % 64 == 0,
+ * I % 128 == 0. */
+int mgen_gemm_bf16_swiglu(const void* x, const void* w, void* gu, void* act, int M, int I, int K, long ldx, long ldw,
+                          long ldgu, long ldact, mgen_stream_t stream);
 
 /* ---- token embedding -----------------------------------------------------------------------------------------
  * nn.Embedding gather (TF models/qwen3/modeling_qwen3.py:352,381) and its index_add backward. ids int64 [T].

@@ -37,7 +37,9 @@ constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
 
 enum OutMode { OUT_BF16 = 0, OUT_F32 = 1, OUT_F32_ACC = 2, OUT_F32_RESID_BF16ROUND = 3, OUT_F32_RESID = 4,
                OUT_F32_ATOMIC = 5 /* internal: split-K form of OUT_F32_ACC */,
-               OUT_BF16_ACC = 6 /* C (bf16) = bf16(C + product): low-rank adapter paths, 128x128 tiles only */ };
+               OUT_BF16_ACC = 6 /* C (bf16) = bf16(C + product): low-rank adapter paths, 128x128 tiles only */,
+               OUT_BF16_SWIGLU = 7 /* internal: C = [gate | up] (N = 2 I) and act = silu(gate) * up, 256x256 tiles whose
+                                      columns are 128 gate columns and the 128 up columns of the same indices */ };
 
 struct GemmArgs {
     const bf16* A;
@@ -56,6 +58,8 @@ struct GemmArgs {
     const bf16* B2;
     long lda2, ldb2;
     int K1;
+    bf16* act;   // OUT_BF16_SWIGLU: [M][N / 2] output of the gated activation
+    long ldact;
 };
 
 // ---- global -> register staging of one operand tile (4 x 16 bytes per thread) -----------------------------
@@ -186,8 +190,13 @@ __global__ __launch_bounds__(256 * WM, WM == 2 ? 2 : (GLDS ? (NJ == 4 ? 2 : 3) :
             if (kSeg && k0 >= g.K1) { k0 -= g.K1; pa = g.A2; pb = g.B2; la = g.lda2; lb = g.ldb2; }
             glds_tile<TA, 8>(pa, la, m0, k0, g.M, st, tid);
             glds_tile<TA, 8>(pa, la, m0 + 128, k0, g.M, st + TILE_BYTES, tid);
-            glds_tile<TB, 8>(pb, lb, n0, k0, g.N, st + 2 * TILE_BYTES, tid);
-            glds_tile<TB, 8>(pb, lb, n0 + 128, k0, g.N, st + 3 * TILE_BYTES, tid);
+            if constexpr (MODE == OUT_BF16_SWIGLU) {   // 128 gate rows of W and the up rows of the same indices
+                glds_tile<TB, 8>(pb, lb, tn * 128, k0, g.N, st + 2 * TILE_BYTES, tid);
+                glds_tile<TB, 8>(pb, lb, g.N / 2 + tn * 128, k0, g.N, st + 3 * TILE_BYTES, tid);
+            } else {
+                glds_tile<TB, 8>(pb, lb, n0, k0, g.N, st + 2 * TILE_BYTES, tid);
+                glds_tile<TB, 8>(pb, lb, n0 + 128, k0, g.N, st + 3 * TILE_BYTES, tid);
+            }
         };
         issue(0, smem);
         const int aoff = TILE_BYTES * (wm >> 7), arow = wm & 127;
@@ -322,6 +331,60 @@ __global__ __launch_bounds__(256 * WM, WM == 2 ? 2 : (GLDS ? (NJ == 4 ? 2 : 3) :
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[i][j][4 * g4 + e] += b[e];
             }
+    }
+    if constexpr (MODE == OUT_BF16_SWIGLU && WM == 2 && NJ == 4) {
+        // Waves 2p and 2p + 1 hold the gate and the up columns of the same 64 rows. Each parks a 64x64 half of its tile
+        // (rounded to bf16: what the separate kernel would read back) in its 8 KiB, writes its own [gate | up] rows,
+        // and computes the gated activation of 32 of the pair's rows from both parked halves. Arithmetic of
+        // swiglu_fwd_kernel<true>: silu in fp32 from the bf16 gate, rounded to bf16, times up, rounded to bf16.
+        char* st = smem + wave * 8192;
+        const char* st_g = smem + (wave & ~1) * 8192;
+        const char* st_u = smem + (wave | 1) * 8192;
+        bf16* C = reinterpret_cast<bf16*>(g.C);
+        const int I = g.N / 2;
+        const int ncol0 = tn * 128 + ((wave & 1) ? I : 0);   // first [gate | up] column of this wave's tile
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();   // the pair's reads of the previous half are done
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int row = 32 * i + (lane & 31);
+                        const int ch = 4 * j + g4;
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][2 * half + j][4 * g4 + e]);
+                        *reinterpret_cast<bf16x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4) + 8 * h) = o;
+                    }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4));
+                const int m = m0 + wm + row;
+                if (m < g.M) *reinterpret_cast<u32x4*>(C + (long)m * g.ldc + ncol0 + 64 * half + ch * 8) = v;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = 32 * (wave & 1) + it * 8 + (lane >> 3), ch = lane & 7;
+                const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+                const bf16x8 gv = *reinterpret_cast<const bf16x8*>(st_g + off);
+                const bf16x8 uv = *reinterpret_cast<const bf16x8*>(st_u + off);
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gf = (float)gv[e];
+                    const float sl = round_bf(gf * (1.f / (1.f + __expf(-gf))));
+                    o[e] = (bf16)(sl * (float)uv[e]);
+                }
+                const int m = m0 + wm + row;
+                if (m < g.M) *reinterpret_cast<bf16x8*>(g.act + (long)m * g.ldact + tn * 128 + 64 * half + ch * 8) = o;
+            }
+        }
+        return;
     }
     if ((MODE == OUT_BF16 || MODE == OUT_BF16_ACC) && (g.ldc & 7) == 0) {
         // bf16 output through LDS: the wave parks its 64x64 sub-tile in its own 8 KiB of the (now idle) staging
@@ -559,6 +622,7 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
         g.lda2 = second->lda2; g.ldb2 = second->ldb2; g.K1 = K;
         K += K2;   // from here on: the total reduction length
     }
+    g.act = nullptr; g.ldact = 0;
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.R = (const float*)resid; g.bias = (const bf16*)bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
     g.nbm = (M + BM - 1) / BM; g.nbn = (N + BN - 1) / BN;
@@ -633,6 +697,30 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
 #endif
 #undef MGEN_GEMM_GO
 }
+
+#if !MGEN_GEMM_SEG
+// gu[M, 2 I] = x[M, K] w[2 I, K]^T (w = [gate rows; up rows]) and act[M, I] = silu(gate) * up in the product's epilogue
+// (reference: Qwen3MLP.forward, transformers models/qwen3/modeling_qwen3.py:81-83, evaluated in bf16 under autocast).
+// 256 x 256 tiles: K a multiple of 64, I a multiple of 128.
+extern "C" int mgen_gemm_bf16_swiglu(const void* x, const void* w, void* gu, void* act, int M, int I, int K, long ldx,
+                                     long ldw, long ldgu, long ldact, hipStream_t stream) {
+    MGEN_REQUIRE(x && w && gu && act && M > 0 && I > 0 && K > 0, "mgen_gemm_bf16_swiglu: bad arguments");
+    MGEN_REQUIRE(K % BK == 0 && I % 128 == 0, "mgen_gemm_bf16_swiglu: needs K %% 64 == 0 and I %% 128 == 0 (K=%d I=%d)", K, I);
+    MGEN_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ldgu % 8 == 0 && ldact % 8 == 0 && ldx >= K && ldw >= K &&
+                     ldgu >= 2 * I && ldact >= I, "mgen_gemm_bf16_swiglu: bad leading dimensions");
+    MGEN_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)gu % 16) == 0 &&
+                     ((uintptr_t)act % 16) == 0, "mgen_gemm_bf16_swiglu: operands must be 16-byte aligned");
+    GemmArgs g;
+    g.A2 = g.B2 = nullptr; g.lda2 = g.ldb2 = 0; g.K1 = 0x7fffffff;
+    g.A = (const bf16*)x; g.B = (const bf16*)w; g.C = gu; g.R = nullptr; g.bias = nullptr;
+    g.M = M; g.N = 2 * I; g.K = K; g.lda = ldx; g.ldb = ldw; g.ldc = ldgu; g.ldr = 0; g.alpha = 1.0f;
+    g.nbm = (M + 255) / 256; g.nbn = I / 128;
+    g.splitk = 1; g.slab_stride = 0; g.kper = K;
+    g.act = (bf16*)act; g.ldact = ldact;
+    MGEN_REQUIRE((long)g.nbm * g.nbn < (1L << 31), "mgen_gemm_bf16_swiglu: grid too large");
+    return launch_one<false, false, OUT_BF16_SWIGLU, true, 4, 2>(g, stream);
+}
+#endif
 
 #if MGEN_GEMM_SEG
 // C = [A | A2] [B | B2]^T in one accumulator: the reduction runs over K indices of (A, B), then K2 of (A2, B2). What

@@ -38,6 +38,7 @@ SIGNATURES = {
     "mgen_dropout_resid": [P, P, P, L, F, U64, P],
     "mgen_swiglu_fwd": [P, P, L, I, I, P],
     "mgen_swiglu_bwd": [P, P, P, L, I, P],
+    "mgen_gemm_bf16_swiglu": [P, P, P, P, I, I, I, L, L, L, L, P],
     "mgen_embedding_fwd": [P, P, P, L, I, L, P, P],
     "mgen_embedding_bwd": [P, P, P, L, I, L, P],
     "mgen_gemm_bf16_bias": [P, P, P, P, P, I, I, I, L, L, L, L, I, I, I, P],

@@ -546,12 +546,13 @@ class MidiLM(GenerationMixin, nn.Module):
             rstd2 = torch.empty(T, dtype=torch.float32, device=dev)
             ops.rmsnorm_fwd(h_mid, v.w_ln2, x2, rstd2, cfg.rms_norm_eps)
             gu = torch.empty(T, 2 * I, dtype=bf, device=dev)
+            act = torch.empty(T, I, dtype=bf, device=dev)
             if fused:   # t = [t_gate | t_up], then one product with the block-diagonal [B_gate, B_up] behind [Wg; Wu]
                 t_gu = lo.fwd_fused_gu(x2, v.s_gu, la, gu, d, I, keys=(lk[2], lk[3]))
-            else:
+                ops.swiglu_fwd(gu, act)
+            elif f32 or la is not None or not ops.linear_swiglu_fwd(x2, v.s_gu, gu, act):
                 ops.linear_fwd(x2, v.s_gu, gu)
-            act = torch.empty(T, I, dtype=bf, device=dev)
-            ops.swiglu_fwd(gu, act)
+                ops.swiglu_fwd(gu, act)
             h_out = torch.empty(T, d, dtype=torch.float32, device=dev)
             if fused:
                 t_down = lo.fwd_fused(act, v.s_down, la, "down", h_out, I, d, ops.OUT_F32_RESID_BF16ROUND, h_mid,

@@ -380,6 +380,19 @@ def swiglu_fwd(gu, act, round_silu=True):
         call("mgen_swiglu_fwd", _p(gu), _p(act), T, I, int(round_silu), _stream())
 
 
+def linear_swiglu_fwd(x, w_gu, gu, act):
+    """gu[T, 2I] = x[T, K] @ w_gu[2I, K]^T and act[T, I] = silu(gate) * up in one launch (bf16; K % 64 == 0,
+    I % 128 == 0). Returns False when the shapes do not fit: the caller then runs the two separate launches."""
+    T, K = x.shape
+    I = act.shape[1]
+    if x.dtype != torch.bfloat16 or not isinstance(w_gu, torch.Tensor) or K % 64 or I % 128 or T < 2048:
+        return False
+    _need_gpu(x, w_gu, gu, act)
+    call("mgen_gemm_bf16_swiglu", _p(x), _p(w_gu), _p(gu), _p(act), T, I, K, x.stride(0), w_gu.stride(0), gu.stride(0),
+         act.stride(0), _stream())
+    return True
+
+
 def swiglu_bwd(gu, dact, dgu):
     T, I = dact.shape
     if gu.dtype == torch.float32:

@@ -332,6 +332,27 @@ def test_swiglu(ops):
     assert rel(dgu.float(), gr.grad) < 1e-2
 
 
+@pytest.mark.parametrize("T,I,K", [(4096, 2048, 512), (2100, 256, 128), (65536, 2048, 512)])
+def test_gate_up_product_with_swiglu_epilogue(ops, T, I, K):
+    """The fused launch against the two separate ones (mgen_gemm_bf16, mgen_swiglu_fwd): same [gate | up] bits, same
+    activation bits; a ragged last row tile included."""
+    g = torch.Generator().manual_seed(11)
+    x = bf(torch.randn(T, K, generator=g)).to(dev())
+    w = bf(torch.randn(2 * I, K, generator=g) * K ** -0.5).to(dev())
+    gu0 = torch.empty(T, 2 * I, dtype=torch.bfloat16, device=dev())
+    act0 = torch.empty(T, I, dtype=torch.bfloat16, device=dev())
+    ops.linear_fwd(x, w, gu0)
+    ops.swiglu_fwd(gu0, act0)
+    gu1 = torch.full((T, 2 * I), 7.0, dtype=torch.bfloat16, device=dev())
+    act1 = torch.full((T, I), 7.0, dtype=torch.bfloat16, device=dev())
+    assert ops.linear_swiglu_fwd(x, w, gu1, act1)
+    assert torch.equal(gu1, gu0)
+    assert torch.equal(act1, act0)
+    if T <= 4096:   # and the product itself against fp32 arithmetic
+        ref = x.float().cpu() @ w.float().cpu().T
+        assert rel(gu1.float(), ref) < 8e-3
+
+
 def test_embedding(ops):
     V, d, T = 1000, 512, 300
     g = torch.Generator().manual_seed(4)
