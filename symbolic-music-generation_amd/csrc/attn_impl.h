@@ -197,6 +197,13 @@ struct TileStream {
 #pragma unroll
         for (int j = 0; j < NP; ++j) issue_piece(j, row0, lds_base, wave, extra);
     }
+    // the same piece with M0 declared clobbered instead of saved and restored (kernels that never rely on M0)
+    __device__ __forceinline__ void issue_piece_m0(int j, int row0, unsigned lds_base, int wave, int extra = 0) const {
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(wave + NW * j) * 1024u);
+        const int soff = __builtin_amdgcn_readfirstlane((row0 + 4 * NW * j) * row_bytes + extra);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     : : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+    }
 };
 
 // per-lane byte offsets inside an IMG256 tile of the two kinds of operand read; rows and columns that are
@@ -1110,6 +1117,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     constexpr int NP = 2 * KS, NV = 4 * DB, NS = 2 * KS, NK = 4 * DB, KH = NK / 4;
     constexpr int pV = NP, pK0 = pV + NV, pS = pK0 + KH, pK1 = pS + NS, NU = pK1 + NK - KH;
     constexpr int LEAD = 4, LEADS = KH < 4 ? KH : 4;      // slots between an LDS read and its MFMA
+    constexpr int DSTEP = (NU - pK0) / 9;                 // slots between two pieces of the next loads
     // vector steps: exponentials (34 steps: multiply-add of element n, exponential of n - 1, packing of pairs). Packed
     // fp32 instructions (v_pk_*_f32) are not used: next to MFMAs they run at a fraction of their stand-alone rate
     constexpr int NV1 = 34, W1A = NU - (pS + NS + 1), W1B = NP - 1, N1A = NV1 * W1A / (W1A + W1B);
@@ -1156,15 +1164,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
     const int nsteps = per_head * group;
     const int skipn = kw0 < S ? wk : per_head;           // tiles of a head sweep before this wave's diagonal tile
 
-    auto issue_step = [&](int s) __attribute__((always_inline)) {
-        const int hrel = HD == 128 ? s / per_head : 0;
-        const int qt0 = (t_first + s % per_head) * 64;
+    // the loads of step s in 9 pieces (4 of the Q tile, 4 of the dO tile, this wave's part of LSE / delta): issued
+    // back to back they hold the wave for ~60 cycles each (a CU takes 64 bytes per cycle from L2), spread over the
+    // MFMA slots behind the barrier they cost a few cycles each
+    // (the step's scalars are worked out once, in plan_step; a piece then costs two scalar adds and the load)
+    int pl_qt0 = 0, pl_extra = 0, pl_hrel = 0;
+    unsigned pl_q = 0, pl_d = 0, pl_l = 0, pl_e = 0;
+    bool pl_on = false;
+    auto plan_step = [&](int s) __attribute__((always_inline)) {
+        pl_on = s < nsteps;
+        pl_hrel = HD == 128 ? s / per_head : 0;
+        pl_qt0 = (t_first + s % per_head) * 64;
+        pl_extra = pl_hrel * HD * 2;
         const unsigned q3 = (unsigned)(s % 3), d2 = (unsigned)(s & 1);
-        tile_issue4(Qs, qt0, lds0 + L::QRING + q3 * TILE, wave, hrel * HD * 2);
-        tile_issue4(dOs, qt0, lds0 + L::DORING + d2 * TILE, wave, hrel * HD * 2);
-        if (wave < L::HPB) Ls.issue((long)(hrel + wave) * S + qt0, lds0 + L::LSER + q3 * L::VECB + wave * 256);
-        else if (wave >= 2 && wave < 2 + L::HPB)
-            Ds.issue((long)(hrel + wave - 2) * S + qt0, lds0 + L::DELR + d2 * L::VECB + (wave - 2) * 256);
+        pl_q = lds0 + L::QRING + q3 * TILE;
+        pl_d = lds0 + L::DORING + d2 * TILE;
+        pl_l = lds0 + L::LSER + q3 * L::VECB;
+        pl_e = lds0 + L::DELR + d2 * L::VECB;
+    };
+    auto issue_piece = [&](int i) __attribute__((always_inline)) {
+        if (!pl_on) return;
+        if (i < 4) Qs.issue_piece_m0(i, pl_qt0, pl_q, wave, pl_extra);
+        else if (i < 8) dOs.issue_piece_m0(i - 4, pl_qt0, pl_d, wave, pl_extra);
+        else if (wave < L::HPB) Ls.issue((long)(pl_hrel + wave) * S + pl_qt0, pl_l + wave * 256);
+        else if (wave >= 2 && wave < 2 + L::HPB) Ds.issue((long)(pl_hrel + wave - 2) * S + pl_qt0, pl_e + (wave - 2) * 256);
+    };
+    auto issue_step = [&](int s) __attribute__((always_inline)) {
+        plan_step(s);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) issue_piece(i);
     };
     {
         TileStream<4> Vs;
@@ -1278,7 +1306,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
 #ifdef MGEN_DKV_STAMPS   // diagnostic build: cycles spent waiting at / issuing loads behind the tile barrier
     unsigned long long st_wait = 0, st_issue = 0, st_begin = __builtin_amdgcn_s_memtime();
 #endif
-    auto sync = [&]() __attribute__((always_inline)) {
+    auto sync = [&](bool spread = false) __attribute__((always_inline)) {
 #ifdef MGEN_DKV_STAMPS
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1288,7 +1316,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
 #ifndef MGEN_DBG_NODMA
-        if (s + 2 < nsteps) issue_step(s + 2);
+        if (spread) plan_step(s + 2);
+        else if (s + 2 < nsteps) issue_step(s + 2);
 #endif
 #ifdef MGEN_DKV_STAMPS
         const unsigned long long t2 = __builtin_amdgcn_s_memtime();
@@ -1373,7 +1402,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs a) {
                     v1_step(std::integral_constant<int, lo + decltype(ic)::value>{}, mnextc, lseb_n, UN);
                 });
             }
-            if constexpr (U == 1 && g == pK0 - 1) sync();
+            if constexpr (U == 1 && g == pK0 - 1) sync(true);
+            if constexpr (U == 1 && g >= pK0 && (g - pK0) % DSTEP == 0 && (g - pK0) / DSTEP < 9) {
+                issue_piece((g - pK0) / DSTEP);
+            }
             SCHED_FENCE();
         });
     };

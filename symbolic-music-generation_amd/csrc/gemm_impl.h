@@ -646,6 +646,11 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
     // N >= 1024 products, -5..10 % on its N = 512 ones (two tile columns leave no second workgroup per CU to
     // cover the first K step and the epilogue).
     const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    // (Measured and not kept for the lm_head input gradient, N = 512 with K = 151936, whose two tile columns read the
+    // long operand twice: 256x256 tiles, 8 % slower, and 128x512 tiles that read it once, 15 % slower - one workgroup
+    // per CU leaves nobody to cover the first K step and the barrier waits. Also not kept: the four images of a stage
+    // requested in front of the four k-steps' MFMAs instead of together behind the barrier: +2..6 % on the forward
+    // products, -14..19 % on the products that read an operand with the transposing LDS read.)
     const bool big = glds && slabs <= 1 && wide_env != 0 && wide_env != 1 && tiles256 >= 256 && N >= 1024 &&
                      out_mode != OUT_BF16_ACC &&
                      (out_mode != OUT_F32_ACC || tiles256 >= 512);

@@ -314,6 +314,21 @@ def test_attention_online_softmax_rescale(ops):
     assert rel(out.float().view(B, S, D), o_ref) < 1e-2
 
 
+def test_gemm_long_reduction_512_columns(ops):
+    """dX[T, 512] = dY[T, K] @ W[K, 512] with a very long K (the lm_head input gradient's shape class): sampled rows
+    against fp32 arithmetic, ragged last row tile included."""
+    M, N, K = 16384 + 72, 512, 32768 + 64
+    g = torch.Generator().manual_seed(5)
+    a = bf(torch.randn(M, K, generator=g) * 0.05).to(dev())
+    b = bf(torch.randn(K, N, generator=g) * 0.05).to(dev())
+    c = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=dev())
+    ops.gemm(a, b, c, M, N, K, K, N, N, trans_a=False, trans_b=True)
+    rows = torch.cat([torch.arange(0, 40), torch.arange(8100, 8140), torch.arange(M - 90, M)])
+    ref = a[rows.to(dev())].float().cpu() @ b.float().cpu()
+    assert rel(c[rows.to(dev())].float(), ref) < 8e-3
+    assert torch.isfinite(c.float()).all()
+
+
 # ----------------------------------------------------------------------------------------------- elementwise
 def test_swiglu(ops):
     T, I = 37, 256
