@@ -253,6 +253,8 @@ def main():
                            "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())
                            if dist.get_backend() == "nccl" else None,
                            "collective": "all_reduce(AVG)" if trainer.reducer._native_avg else "all_reduce(SUM) / N",
+                           "path": "mgen_comm (RCCL through the C-ABI)" if trainer.reducer._comm is not None
+                           else "torch.distributed",
                            "buckets": [{"bytes": b, "dtype": d} for b, d in log],
                            "bytes_per_step": sum(b for b, _ in log)}
         if world == 1 and args.decode_tokens > 0:

@@ -319,6 +319,25 @@ int mgen_sample(const void* logits, long ld, int B, int V, int is_bf16, int do_s
 int mgen_philox_exponential(float* out, long ld, int B, int V, unsigned long long seed, unsigned long long offset,
                             mgen_stream_t stream);
 
+/* ---- data-parallel gradient exchange over RCCL -----------------------------------------------------------------
+ * What lightning's DDP strategy does behind lightning.Trainer(...) (/root/reference/src/train.py:63-72,
+ * src/train_aria.py:322-336: torch DistributedDataParallel all-reduces gradient buckets during backward and divides by
+ * the world size). One communicator per process (one process per GPU). RCCL is opened with dlopen on first use.
+ *   mgen_comm_unique_id     rank 0 makes the 128-byte id; every rank needs the same bytes (hand them over out of band)
+ *   mgen_comm_init          joins the communicator of `world` ranks on `device`
+ *   mgen_comm_allreduce_bucket  in-place fp32 mean (average != 0) or sum of buf[0..n) over the ranks, enqueued on the
+ *                           communicator's own stream behind what compute_stream holds now; returns at once
+ *   mgen_comm_wait          makes `stream` wait for every bucket enqueued so far; optional outputs: bytes and buckets
+ *                           reduced since the previous wait
+ *   mgen_comm_rccl_version  the RCCL version code (e.g. 22205) */
+typedef struct mgen_comm mgen_comm_t;
+int mgen_comm_unique_id(void* id128);
+int mgen_comm_rccl_version(int* version);
+int mgen_comm_init(mgen_comm_t** comm, const void* id128, int rank, int world, int device);
+int mgen_comm_allreduce_bucket(mgen_comm_t* comm, float* buf, long n, int average, mgen_stream_t compute_stream);
+int mgen_comm_wait(mgen_comm_t* comm, mgen_stream_t stream, long* bytes, int* buckets);
+int mgen_comm_destroy(mgen_comm_t* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,12 @@ SIGNATURES = {
     "mgen_swiglu_fwd": [P, P, L, I, I, P],
     "mgen_swiglu_bwd": [P, P, P, L, I, P],
     "mgen_gemm_bf16_swiglu": [P, P, P, P, I, I, I, L, L, L, L, P],
+    "mgen_comm_unique_id": [P],
+    "mgen_comm_rccl_version": [P],
+    "mgen_comm_init": [P, P, I, I, I],
+    "mgen_comm_allreduce_bucket": [P, P, L, I, P],
+    "mgen_comm_wait": [P, P, P, P],
+    "mgen_comm_destroy": [P],
     "mgen_embedding_fwd": [P, P, P, L, I, L, P, P],
     "mgen_embedding_bwd": [P, P, P, L, I, L, P],
     "mgen_gemm_bf16_bias": [P, P, P, P, P, I, I, I, L, L, L, L, I, I, I, P],

@@ -33,6 +33,12 @@ class GradReducer:
         self._ranges = {tag: (s, e) for tag, s, e in model.grad_ranges()}
         # RCCL averages in the collective; gloo (CPU rehearsal of the same logic) has no AVG: sum, then divide
         self._native_avg = self.world > 1 and dist.get_backend(group) == "nccl"
+        # MGEN_NATIVE_COMM=1: the buckets go through the library's own RCCL communicator (mgen_comm_*) instead of
+        # torch.distributed's; same collective, same overlap (RCCL's stream beside the compute stream)
+        self._comm = None
+        if self._native_avg and os.environ.get("MGEN_NATIVE_COMM") == "1":
+            from .comm import NativeComm
+            self._comm = NativeComm(group=group)
         self._lora = getattr(model, "lora", None)   # adapters: one small buffer, reduced in wait()
         if self.world > 1 and self._lora is None:
             model._grad_hook = self._on_range_done
@@ -48,6 +54,9 @@ class GradReducer:
 
     def _start(self, buf):
         """Begin the reduction of one slice; returns something with .wait()."""
+        if self._comm is not None:
+            self._comm.allreduce_(buf, average=True)
+            return self._comm
         if self._native_avg:
             return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         if buf.is_cuda:
