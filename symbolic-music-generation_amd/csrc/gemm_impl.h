@@ -23,6 +23,7 @@
 // and a low-rank adapter product in one accumulator). Separate translation units keep the plain kernels' code free
 // of the second pair's address selection.
 #include "common.h"
+#include "gemm_rs.h"
 
 #ifndef MGEN_GEMM_SEG
 #error "include through gemm.hip or gemm_seg.hip"
@@ -622,6 +623,12 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
         g.lda2 = second->lda2; g.ldb2 = second->ldb2; g.K1 = K;
         K += K2;   // from here on: the total reduction length
     }
+#if !MGEN_GEMM_SEG
+    // short reduction, many rows, bf16 output: the kernel that keeps the row panel in registers (gemm_rs.hip)
+    if (!transA && !transB && out_mode == OUT_BF16 && !bias && !second && alpha == 1.0f && slabs <= 1 &&
+        mgen_gemm_rs_fits(M, N, K, lda, ldb, ldc))
+        return mgen_gemm_rs_launch(A, B, C, nullptr, M, N, 0, lda, ldb, ldc, 0, stream);
+#endif
     g.act = nullptr; g.ldact = 0;
     g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.R = (const float*)resid; g.bias = (const bf16*)bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.alpha = alpha;
@@ -715,6 +722,8 @@ extern "C" int mgen_gemm_bf16_swiglu(const void* x, const void* w, void* gu, voi
                      ldgu >= 2 * I && ldact >= I, "mgen_gemm_bf16_swiglu: bad leading dimensions");
     MGEN_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)gu % 16) == 0 &&
                      ((uintptr_t)act % 16) == 0, "mgen_gemm_bf16_swiglu: operands must be 16-byte aligned");
+    if (I % 32 == 0 && mgen_gemm_rs_fits(M, 2 * I, K, ldx, ldw, ldgu))
+        return mgen_gemm_rs_launch(x, w, gu, act, M, 2 * I, I, ldx, ldw, ldgu, ldact, stream);
     GemmArgs g;
     g.A2 = g.B2 = nullptr; g.lda2 = g.ldb2 = 0; g.K1 = 0x7fffffff;
     g.A = (const bf16*)x; g.B = (const bf16*)w; g.C = gu; g.R = nullptr; g.bias = nullptr;

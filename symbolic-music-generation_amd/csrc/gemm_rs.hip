@@ -1,0 +1,399 @@
+// bf16 GEMM for products with a SHORT reduction (K = 512) and many rows: C[M,N] = A[M,512] * B[N,512]^T.
+//
+// Serves the forward projections out of the residual stream of the d = 512 decoders (QKV, gate/up with the SwiGLU
+// gate, the lm_head logits; reference: nn.Linear calls in transformers models/qwen3/modeling_qwen3.py:76-83,225-236
+// and the lm_head of Qwen3ForCausalLM.forward).
+//
+// With K = 512 a classic tile loop spends a third of its time outside the K loop and moves every operand byte
+// through LDS once per 256 output columns. Here the token operand never goes back to memory: a workgroup of four
+// waves (one per SIMD, 512 registers each) owns 256 token rows, and each wave keeps ITS 64 rows x 512 reduction
+// indices as 2 x 32 MFMA operand fragments in 256 registers for the whole kernel. The weight rows stream past in
+// blocks of 32 rows (32 KiB) through a four-slot LDS ring filled by LDS-DMA; every fragment read from LDS feeds two
+// MFMAs (the wave's two 32-row token tiles), the accumulators of a block are a single chain of 32 dependent
+// v_mfma_f32_32x32x16_bf16 per tile. One barrier per block; three blocks of loads in flight; the output of two
+// blocks (64 rows x 64 columns per wave) goes through a per-wave LDS image so that whole 128-byte row segments
+// are stored. All workgroups stream the same weight rows at the same pace, so the stream is served by the L2.
+//
+// LDS image of a 32-row block (also used for the 128-row pieces of the token panel on their way into the
+// registers): row r = 1024 bytes = 64 chunks of 16 bytes; chunk c sits at position (c & 48) | ((c & 15) ^ (r & 15)).
+// The sixteen lanes that a ds_read_b128 serves together hold sixteen different values of r & 15, i.e. sixteen
+// different 16-byte bank groups. The LDS-DMA writes a row as one linear KiB, so the permutation is applied to each
+// lane's SOURCE address.
+#include "common.h"
+#include "gemm_rs.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int RS_K = 512, RS_KS = RS_K / 16;
+constexpr int RS_ROWS = 256;                       // token rows per workgroup
+constexpr int RS_SLOT = 32 * RS_K * 2;             // one block of 32 rows: 32 KiB
+constexpr int RS_NSLOT = 4;
+constexpr int RS_AHEAD = 3;                        // LDS fragment reads in flight ahead of their MFMAs
+constexpr int RS_STAGE = 8192;                     // per-wave output image: 64 rows x 128 bytes
+constexpr int RS_LDS = RS_NSLOT * RS_SLOT + 4 * RS_STAGE;   // 160 KiB
+
+struct RsArgs {
+    const bf16* A;
+    const bf16* B;
+    bf16* C;
+    bf16* act;
+    long lda, ldb, ldc, ldact;
+    int M, N;             // N = output columns of C (SwiGLU form: 2 I)
+    int I;                // SwiGLU form: gate rows [0, I), up rows [I, 2 I) of B
+    int nrp;              // 256-row panels
+    int parts;            // the column range is cut into `parts` runs of `ppp` 64-column pairs
+    int ppp, npairs;
+    int xcd_map;          // grid is a multiple of 8: workgroups of one XCD share a run
+};
+
+// raw buffer descriptor over `bytes` bytes from p on (reads past the end return zeros)
+__device__ __forceinline__ u32x4 make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+
+// The wave's 8 rows (wave + 4 q + 16 half) of a 32-row block whose first row starts `soff` bytes into the buffer,
+// into the slot at LDS byte address `dst0` (+ 1024 * row). One asm statement: the compiler never learns that LDS
+// writes are pending, all waiting is done by hand with counted s_waitcnt vmcnt.
+__device__ __forceinline__ void rs_issue(const u32x4& rsrc, const int (&voff)[4], unsigned dst0, int soff, int step16) {
+    asm volatile(
+        "s_mov_b32 m0, %[dst]\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "buffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "buffer_load_dwordx4 %[v2], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "buffer_load_dwordx4 %[v3], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\ts_add_u32 %[so], %[so], %[st]\n\t"
+        "buffer_load_dwordx4 %[v0], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "buffer_load_dwordx4 %[v1], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "buffer_load_dwordx4 %[v2], %[rs], %[so] offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "buffer_load_dwordx4 %[v3], %[rs], %[so] offen lds"
+        : [so] "+s"(soff)
+        : [dst] "s"(dst0), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [rs] "s"(rsrc),
+          [st] "s"(step16)
+        : "memory", "m0", "scc");
+}
+
+// one of those 8 rows as a statement of its own (piece q: row wave + 4 (q & 3) + 16 (q >> 2))
+__device__ __forceinline__ void rs_issue_piece(const u32x4& rsrc, int voff, unsigned dst, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 : : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void rs_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// SW: B = [gate rows; up rows] (2 I rows), C = [gate | up] and act = silu(gate) * up
+// DBG (timing experiments only, results are wrong): 1 no global stores, 2 no output code at all, 4 no loads inside
+// the loop, 8 no MFMAs
+template <bool SW, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    constexpr int S = (DBG & 3) ? 0 : (SW ? 12 : 8);   // global stores of a wave per 64-column pair
+
+    int part, rp;
+    if (g.xcd_map) {
+        const int x = blockIdx.x & 7;
+        part = x % g.parts;
+        rp = (blockIdx.x >> 3) * (8 / g.parts) + x / g.parts;
+    } else {
+        part = blockIdx.x % g.parts;
+        rp = blockIdx.x / g.parts;
+    }
+    const int p0 = part * g.ppp;
+    const int p1 = min(g.npairs, p0 + g.ppp);
+    const int nblk = 2 * (p1 - p0);
+    if (nblk <= 0 || rp >= g.nrp) return;
+
+    const unsigned lds0 = lds_addr(smem);
+    const int ldb2 = (int)(g.ldb * 2);
+    const int brows = SW ? 2 * g.I : g.N;
+    const u32x4 rsB = make_rsrc(g.B, (unsigned)(((long)(brows - 1) * g.ldb + RS_K) * 2));
+    int voffB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = wave + 4 * q;
+        const int pos = 16 * ((lane & 48) | ((lane & 15) ^ rr));
+        voffB[q] = rr * ldb2 + pos;
+    }
+    // reader: row r of a block, k-step ks -> chunk 2 ks + h; ks & 7 picks one of 8 per-lane offsets, ks >> 3 adds 256
+    int raddr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) raddr[e] = r * 1024 + ((32 * e + 16 * h) ^ (16 * (r & 15)));
+
+    // ---- the weight stream: blocks of one run in rotated order, so that workgroups that work in step do not all
+    // store the same 128-byte column segment of their rows at the same time (one memory channel for the whole chip
+    // whenever the row pitch is a multiple of the channel interleave)
+    const int npp = p1 - p0;
+    const int rot = (rp & 15) % npp;
+    auto pair_of = [&](int jp) { int q = jp + rot; if (q >= npp) q -= npp; return p0 + q; };
+    auto issue_block = [&](int jl) {
+        const int jc = min(jl, nblk - 1);
+        const int gp = pair_of(jc >> 1);
+        const int row = SW ? ((jc & 1) * g.I + 32 * gp) : (64 * gp + 32 * (jc & 1));
+        rs_issue(rsB, voffB, lds0 + (jl & 3) * RS_SLOT + wave * 1024, row * ldb2, 16 * ldb2);
+    };
+    // the same block piece by piece (piece q behind k-step 4 q + 2 of the block that is being multiplied)
+    auto block_soff = [&](int jl) {
+        const int jc = min(jl, nblk - 1);
+        const int gp = pair_of(jc >> 1);
+        const int row = SW ? ((jc & 1) * g.I + 32 * gp) : (64 * gp + 32 * (jc & 1));
+        return row * ldb2;
+    };
+    // ---- the token panel: 2 x 128 rows through the ring (whole 1 KiB rows, like the weight blocks) into registers:
+    // fragment (mt, ks) of a lane = row 32 mt + r, reduction indices 16 ks + 8 h .. + 7
+    const int mrow0 = rp * RS_ROWS + wave * 64;
+    bf16x8 Af[2][RS_KS];
+    {
+        const int lda2 = (int)(g.lda * 2);
+        const u32x4 rsA = make_rsrc(g.A, (unsigned)(((long)(g.M - 1) * g.lda + RS_K) * 2));
+        int voffA[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) voffA[q] = voffB[q] + (wave + 4 * q) * (lda2 - ldb2);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+                rs_issue(rsA, voffA, lds0 + sl * RS_SLOT + wave * 1024, (rp * RS_ROWS + 128 * f + 32 * sl) * lda2,
+                         16 * lda2);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if ((wave >> 1) == f) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const char* sb = smem + (2 * (wave & 1) + mt) * RS_SLOT;
+#pragma unroll
+                    for (int ks = 0; ks < RS_KS; ++ks)
+                        Af[mt][ks] = *reinterpret_cast<const bf16x8*>(sb + raddr[ks & 7] + 256 * (ks >> 3));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    issue_block(0);
+    issue_block(1);
+    issue_block(2);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // The output work rides behind the MFMAs of the following blocks: the two tiles a block has finished are rounded
+    // and parked in the wave's LDS image behind the first 8 k-steps of the next block (which accumulates into the
+    // other two tiles); once both halves of a pair are parked (8 k-steps into the next pair) the image is read back
+    // as whole 128-byte row segments and stored, one slice per two k-steps.
+    f32x16 acc[2][2];
+    char* st = smem + RS_NSLOT * RS_SLOT + wave * RS_STAGE;
+
+    // slice t (0..7) of parking the tiles acc[.][j]: tile row block i = t >> 2, column group g4 -> 8 bytes per lane
+    auto park = [&](int j, int t) {
+        const int i = t >> 2, g4 = t & 3;
+        const int row = 32 * i + r;
+        const int ch = 4 * j + g4;
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][j][4 * g4 + e]);
+        *reinterpret_cast<bf16x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4) + 8 * h) = o;
+    };
+    // plain form, slice it (0..7): 8 rows x 128 bytes of the image
+    auto unpark = [&](int it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        return *reinterpret_cast<const u32x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4));
+    };
+    auto store_plain = [&](int it, int gp, const u32x4& v) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        u32x4* dst = reinterpret_cast<u32x4*>(g.C + (long)(mrow0 + row) * g.ldc + 64 * gp + ch * 8);
+        // non-temporal: the output is a stream several times the size of the L2, whose capacity belongs to the weight
+        // rows every workgroup re-reads (measured with plain stores: 2.3 TB/s of output, with these 4.4-4.7 TB/s)
+        if (DBG & 1) asm volatile("" ::"v"(v));
+        else if (DBG & 64) *dst = v;
+        else __builtin_nontemporal_store(v, dst);
+    };
+    // SwiGLU form, slice it (0..3): 16 rows; chunks 0..3 of a row are 32 gate columns, chunks 4..7 the up columns of
+    // the same indices. Arithmetic of the separate kernel: silu in fp32 from the bf16 gate, rounded to bf16, times up
+    auto store_swiglu = [&](int it, int gp) {
+        const int row = it * 16 + (lane >> 2), ch = lane & 3;
+        const bf16x8 gv = *reinterpret_cast<const bf16x8*>(st + row * 128 + ((ch ^ (row & 7)) << 4));
+        const bf16x8 uv = *reinterpret_cast<const bf16x8*>(st + row * 128 + (((4 + ch) ^ (row & 7)) << 4));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gf = (float)gv[e];
+            const float sl = round_bf(gf * (1.f / (1.f + __expf(-gf))));
+            o[e] = (bf16)(sl * (float)uv[e]);
+        }
+        bf16* c = g.C + (long)(mrow0 + row) * g.ldc + 32 * gp + ch * 8;
+        __builtin_nontemporal_store(gv, reinterpret_cast<bf16x8*>(c));
+        __builtin_nontemporal_store(uv, reinterpret_cast<bf16x8*>(c + g.I));
+        __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(g.act + (long)(mrow0 + row) * g.ldact + 32 * gp + ch * 8));
+    };
+
+    // Fragments of the first RS_AHEAD k-steps of the coming block, requested at the end of the block before it. That
+    // is legal because a block is waited for one barrier early: the wave waits for ITS pieces of block jl + 1 in
+    // front of the barrier that opens block jl, so behind that barrier block jl + 1 is complete for every wave.
+    bf16x8 fpre[RS_AHEAD];
+#pragma unroll
+    for (int ks = 0; ks < RS_AHEAD; ++ks) fpre[ks] = *reinterpret_cast<const bf16x8*>(smem + raddr[ks & 7] + 256 * (ks >> 3));
+
+    // one pair of blocks; FIRST: there is no earlier block whose tiles wait to be parked and stored
+    auto do_pair = [&](int jp, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const int gpp = FIRST ? 0 : pair_of(jp - 1);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int jl = 2 * jp + nb;
+            // this wave's pieces of block jl + 1 have landed: younger are the 8 pieces of block jl + 2 and, when the
+            // block before this one carried a pair's stores (nb == 1), those stores. Every wave's LDS reads of block
+            // jl - 1 have returned (they fed MFMAs that are issued); past the barrier its slot takes block jl + 3.
+            if (!(DBG & 32)) {
+                if (nb == 0) rs_wait_vm<8>();
+                else rs_wait_vm<8 + S>();
+            }
+            asm volatile("s_barrier" ::: "memory");
+            const int nsoff = __builtin_amdgcn_readfirstlane(block_soff(jl + 3));
+            const unsigned ndst = __builtin_amdgcn_readfirstlane(lds0 + ((jl + 3) & 3) * RS_SLOT + wave * 1024);
+            const char* sb = smem + (jl & 3) * RS_SLOT;
+            const char* sbn = smem + ((jl + 1) & 3) * RS_SLOT;
+            const bool out = !(FIRST && nb == 0) && !(DBG & 2);   // tiles of block jl - 1 to park
+            bf16x8 fb[RS_KS];
+            u32x4 ov[2] = {};
+#pragma unroll
+            for (int ks = 0; ks < RS_AHEAD; ++ks) fb[ks] = fpre[ks];
+#pragma unroll
+            for (int ks = 0; ks < RS_KS; ++ks) {
+                // the fragment of k-step ks + RS_AHEAD is requested in front of the two MFMAs of step ks
+                if (ks + RS_AHEAD < RS_KS)
+                    fb[ks + RS_AHEAD] = *reinterpret_cast<const bf16x8*>(sb + raddr[(ks + RS_AHEAD) & 7] +
+                                                                         256 * ((ks + RS_AHEAD) >> 3));
+                else
+                    fpre[ks + RS_AHEAD - RS_KS] = *reinterpret_cast<const bf16x8*>(
+                        sbn + raddr[(ks + RS_AHEAD - RS_KS) & 7] + 256 * ((ks + RS_AHEAD - RS_KS) >> 3));
+                if (DBG & 8) {
+                    asm volatile("" ::"v"(fb[ks]));
+                } else if (ks == 0) {
+                    const f32x16 z = {};
+                    acc[0][nb] = mfma32(fb[ks], Af[0][ks], z);
+                    acc[1][nb] = mfma32(fb[ks], Af[1][ks], z);
+                } else {
+                    acc[0][nb] = mfma32(fb[ks], Af[0][ks], acc[0][nb]);
+                    acc[1][nb] = mfma32(fb[ks], Af[1][ks], acc[1][nb]);
+                }
+                // piece q of block jl + 3 behind k-step 4 q + 2 (the last one behind the block's last store)
+                if (!(DBG & 4) && (ks & 3) == 2) {
+                    const int q = ks >> 2;
+                    rs_issue_piece(rsB, voffB[q & 3], ndst + 0x1000 * q, nsoff + (q >> 2) * 16 * ldb2);
+                }
+                if (out) {
+                    if (ks < 8) park(nb ^ 1, ks);
+                    if (nb == 0 && !SW) {
+                        // image slice it is requested behind step 8 + 2 it and stored behind step 11 + 2 it
+                        if (ks >= 8 && ks < 24 && !(ks & 1)) ov[(ks >> 1) & 1] = unpark((ks - 8) >> 1);
+                        if (ks >= 11 && ks < 27 && (ks & 1)) store_plain((ks - 11) >> 1, gpp, ov[((ks - 3) >> 1) & 1]);
+                    }
+                    if (nb == 0 && SW) {
+                        if (ks >= 8 && ks < 24 && (ks & 3) == 3) store_swiglu((ks - 8) >> 2, gpp);
+                    }
+                }
+            }
+        }
+    };
+    using yes = std::integral_constant<bool, true>;
+    using no = std::integral_constant<bool, false>;
+
+    do_pair(0, yes{});
+    for (int jp = 1; jp < npp; ++jp) do_pair(jp, no{});
+    // the last block's tiles and the last pair's stores
+    if (!(DBG & 2)) {
+        const int gpl = pair_of(npp - 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) park(1, t);
+        if (!SW) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) store_plain(it, gpl, unpark(it));
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) store_swiglu(it, gpl);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be pending when the wave ends
+}
+
+template <bool SW, int DBG = 0>
+int rs_launch(const RsArgs& g, hipStream_t s) {
+    static bool asked[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!asked[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rs_kernel<SW, DBG>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, RS_LDS);
+        if (e != hipSuccess) {
+            mgen_set_error("mgen_gemm_bf16: cannot reserve %d bytes of LDS: %s", RS_LDS, hipGetErrorString(e));
+            return MGEN_ELAUNCH;
+        }
+        asked[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_rs_kernel<SW, DBG>), dim3(g.nrp * g.parts), dim3(256), RS_LDS, s, g);
+    return mgen_check_launch("mgen_gemm_bf16");
+}
+
+}  // namespace
+
+bool mgen_gemm_rs_fits(int M, int N, int K, long lda, long ldb, long ldc) {
+    const char* e = getenv("MGEN_GEMM_RS");   // MGEN_GEMM_RS=0: never (same-process A/B runs)
+    const bool off = e && e[0] == '0';
+    // whole 256-row panels only: the counted waits of the kernel assume that every store instruction is issued
+    if (off || K != RS_K || N % 64 != 0 || N < 1024 || M < 64 * RS_ROWS || M % RS_ROWS != 0) return false;
+    if (lda < RS_K || ldb < RS_K || (lda % 8) || (ldb % 8) || (ldc % 8)) return false;
+    // byte offsets inside the buffer descriptors are 32-bit
+    if ((long)M * lda * 2 >= (1L << 32) || (long)N * ldb * 2 >= (1L << 32)) return false;
+    return true;
+}
+
+// I > 0: SwiGLU form (B has 2 I rows, C = [gate | up] with 2 I columns, act [M][I]); else plain (B has N rows)
+int mgen_gemm_rs_launch(const void* A, const void* B, void* C, void* act, int M, int N, int I, long lda, long ldb,
+                        long ldc, long ldact, hipStream_t stream) {
+    RsArgs g;
+    g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = (bf16*)C; g.act = (bf16*)act;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldact = ldact;
+    g.M = M; g.N = N; g.I = I;
+    g.nrp = (M + RS_ROWS - 1) / RS_ROWS;
+    g.npairs = I > 0 ? I / 32 : N / 64;
+    // fill the chip: cut the column range while there are fewer workgroups than CUs (runs of at least 8 pairs)
+    int parts = 1;
+    while (parts < 8 && g.nrp * parts < 256 && g.npairs / (parts * 2) >= 8) parts *= 2;
+    g.parts = parts;
+    g.ppp = (g.npairs + parts - 1) / parts;
+    g.xcd_map = ((g.nrp * parts) % 8) == 0;
+#ifdef MGEN_RS_EXPERIMENTS
+    if (const char* e = getenv("MGEN_RS_DBG")) {
+        switch (atoi(e)) {
+            case 1: return rs_launch<false, 1>(g, stream);
+            case 2: return rs_launch<false, 2>(g, stream);
+            case 4: return rs_launch<false, 4>(g, stream);
+            case 6: return rs_launch<false, 6>(g, stream);
+            case 8: return rs_launch<false, 8>(g, stream);
+            case 10: return rs_launch<false, 10>(g, stream);
+            case 14: return rs_launch<false, 14>(g, stream);
+            case 64: return rs_launch<false, 64>(g, stream);
+            case 32: return rs_launch<false, 32>(g, stream);
+            case 33: return rs_launch<false, 33>(g, stream);
+            case 9: return rs_launch<false, 9>(g, stream);
+            case 12: return rs_launch<false, 12>(g, stream);
+
+        }
+    }
+#endif
+    return I > 0 ? rs_launch<true>(g, stream) : rs_launch<false>(g, stream);
+}
