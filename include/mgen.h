@@ -258,6 +258,12 @@ int mgen_notes_to_events(const float* rows, long n, float ticks_per_second, int*
 
 /* dtype conversion: kind 0 fp32 -> bf16, 1 bf16 -> fp32. */
 int mgen_cast(const void* in, void* out, long n, int kind, mgen_stream_t stream);
+/* out[b] [C][R] = in[b] [R][C]^T for nbatch bf16 matrices bs_in / bs_out elements apart. Replaces the transposed
+ * operand read inside autograd's mm backward (grad_input = grad_output @ weight, torch/csrc/autograd FunctionsManual
+ * mm_mat1_backward as reached from nn.Linear in models/qwen3/modeling_qwen3.py:76-83): the host keeps transposed bf16
+ * copies of the weights whose input-gradient product has a 512-long reduction, refreshed once per optimizer step. */
+int mgen_transpose_bf16(const void* in, void* out, int R, int C, long ldin, long ldout, int nbatch, long bs_in,
+                        long bs_out, mgen_stream_t stream);
 
 /* ---- shifted cross entropy (ForCausalLMLoss, TF loss/loss_utils.py:49-71) -----------------------------------
  * labels int64 [B][S]; row (b,s) is scored against labels[b][s+1]. */

@@ -141,6 +141,34 @@ extern "C" int mgen_embedding_bwd(const long* ids, const float* dout, float* dta
     return mgen_check_launch("mgen_embedding_bwd");
 }
 
+// out[b][c][r] = in[b][r][c] for `nbatch` matrices of R x C 16-bit elements (64 x 64 tiles through LDS, 128-byte
+// row segments on both sides; the 65-element pitch keeps the column reads on different banks)
+__global__ __launch_bounds__(256) void transpose16_kernel(const unsigned short* __restrict__ in,
+                                                          unsigned short* __restrict__ out, int R, int C, long ldin,
+                                                          long ldout, long bs_in, long bs_out) {
+    __shared__ unsigned short tile[64][65];
+    in += (long)blockIdx.z * bs_in;
+    out += (long)blockIdx.z * bs_out;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        tile[i][tx] = (r0 + i < R && c0 + tx < C) ? in[(long)(r0 + i) * ldin + c0 + tx] : (unsigned short)0;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < C && r0 + tx < R) out[(long)(c0 + i) * ldout + r0 + tx] = tile[tx][i];
+}
+
+// Transposed copies of bf16 matrices (weights whose input-gradient product wants the reduction index contiguous):
+// out[b] [C][R] = in[b] [R][C]^T, b = 0 .. nbatch-1, matrices bs_in / bs_out elements apart.
+extern "C" int mgen_transpose_bf16(const void* in, void* out, int R, int C, long ldin, long ldout, int nbatch,
+                                   long bs_in, long bs_out, hipStream_t stream) {
+    MGEN_REQUIRE(in && out && R > 0 && C > 0 && nbatch > 0 && nbatch < 65536 && ldin >= C && ldout >= R,
+                 "mgen_transpose_bf16: bad arguments");
+    hipLaunchKernelGGL(transpose16_kernel, dim3((C + 63) / 64, (R + 63) / 64, nbatch), dim3(256), 0, stream,
+                       (const unsigned short*)in, (unsigned short*)out, R, C, ldin, ldout, bs_in, bs_out);
+    return mgen_check_launch("mgen_transpose_bf16");
+}
+
 // kind: 0 = fp32 -> bf16, 1 = bf16 -> fp32
 extern "C" int mgen_cast(const void* in, void* out, long n, int kind, hipStream_t stream) {
     MGEN_REQUIRE(in && out && n > 0, "mgen_cast: bad arguments");

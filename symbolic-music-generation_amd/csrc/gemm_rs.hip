@@ -248,8 +248,13 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     for (int ks = 0; ks < RS_AHEAD; ++ks) fpre[ks] = *reinterpret_cast<const bf16x8*>(smem + raddr[ks & 7] + 256 * (ks >> 3));
 
     // one pair of blocks; FIRST: there is no earlier block whose tiles wait to be parked and stored
-    auto do_pair = [&](int jp, auto first_tag) {
+    // WV = this wave's index as a constant: the four waves run four copies of the loop that differ only in WHEN
+    // they issue their vector-memory instructions (LDS-DMA pieces behind k-step 4 q + WV, stores one k-step later in
+    // the odd waves), so that the four do not queue at the CU's one memory pipeline at the same moments
+    auto do_pair = [&](int jp, auto first_tag, auto wave_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int WV = decltype(wave_tag)::value;
+        constexpr int WO = WV & 1;
         const int gpp = FIRST ? 0 : pair_of(jp - 1);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
@@ -290,8 +295,8 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
                     acc[0][nb] = mfma32(fb[ks], Af[0][ks], acc[0][nb]);
                     acc[1][nb] = mfma32(fb[ks], Af[1][ks], acc[1][nb]);
                 }
-                // piece q of block jl + 3 behind k-step 4 q + 2 (the last one behind the block's last store)
-                if (!(DBG & 4) && (ks & 3) == 2) {
+                // piece q of block jl + 3 behind k-step 4 q + WV (the last one, 28 + WV, behind the block's last store)
+                if (!(DBG & 4) && (ks & 3) == WV) {
                     const int q = ks >> 2;
                     rs_issue_piece(rsB, voffB[q & 3], ndst + 0x1000 * q, nsoff + (q >> 2) * 16 * ldb2);
                 }
@@ -299,11 +304,13 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
                     if (ks < 8) park(nb ^ 1, ks);
                     if (nb == 0 && !SW) {
                         // image slice it is requested behind step 8 + 2 it and stored behind step 11 + 2 it
-                        if (ks >= 8 && ks < 24 && !(ks & 1)) ov[(ks >> 1) & 1] = unpark((ks - 8) >> 1);
-                        if (ks >= 11 && ks < 27 && (ks & 1)) store_plain((ks - 11) >> 1, gpp, ov[((ks - 3) >> 1) & 1]);
+                        const int kk = ks - WO;   // odd waves: everything one k-step later
+                        if (kk >= 8 && kk < 24 && !(kk & 1)) ov[(kk >> 1) & 1] = unpark((kk - 8) >> 1);
+                        if (kk >= 11 && kk < 27 && (kk & 1)) store_plain((kk - 11) >> 1, gpp, ov[((kk - 3) >> 1) & 1]);
                     }
                     if (nb == 0 && SW) {
-                        if (ks >= 8 && ks < 24 && (ks & 3) == 3) store_swiglu((ks - 8) >> 2, gpp);
+                        const int kk = ks - 2 * WO;   // odd waves: two k-steps later
+                        if (kk >= 8 && kk < 24 && (kk & 3) == 3) store_swiglu((kk - 8) >> 2, gpp);
                     }
                 }
             }
@@ -312,8 +319,16 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     using yes = std::integral_constant<bool, true>;
     using no = std::integral_constant<bool, false>;
 
-    do_pair(0, yes{});
-    for (int jp = 1; jp < npp; ++jp) do_pair(jp, no{});
+    auto run = [&](auto wave_tag) {
+        do_pair(0, yes{}, wave_tag);
+        for (int jp = 1; jp < npp; ++jp) do_pair(jp, no{}, wave_tag);
+    };
+    switch (wave) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        default: run(std::integral_constant<int, 3>{}); break;
+    }
     // the last block's tiles and the last pair's stores
     if (!(DBG & 2)) {
         const int gpl = pair_of(npp - 1);
@@ -387,6 +402,7 @@ int mgen_gemm_rs_launch(const void* A, const void* B, void* C, void* act, int M,
             case 10: return rs_launch<false, 10>(g, stream);
             case 14: return rs_launch<false, 14>(g, stream);
             case 64: return rs_launch<false, 64>(g, stream);
+            case 5: return rs_launch<false, 5>(g, stream);
             case 32: return rs_launch<false, 32>(g, stream);
             case 33: return rs_launch<false, 33>(g, stream);
             case 9: return rs_launch<false, 9>(g, stream);

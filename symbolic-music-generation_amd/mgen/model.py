@@ -127,6 +127,9 @@ class MidiLM(GenerationMixin, nn.Module):
         self.flat_shadow_lo = torch.zeros(off, dtype=torch.bfloat16, device=dev) \
             if compute_dtype == torch.float32 else None
         self._shadow_version = -1
+        self._shadow_epoch = 0     # counts rewrites of the bf16 shadow (transposed copies follow it)
+        self._wt = None            # transposed bf16 copies of o_proj / down_proj, see _dgrad_weights_t
+        self._wt_epoch = -1
         for name, shape in layout:
             prm = nn.Parameter(self._view(self.flat_param, name), requires_grad=True)
             prm.grad = self._view(self.flat_grad, name)
@@ -298,11 +301,36 @@ class MidiLM(GenerationMixin, nn.Module):
             else:
                 ops.cast(self.flat_param, self.flat_shadow)
             self._shadow_version = self.flat_param._version
+            self._shadow_epoch += 1
 
     def mark_shadow_fresh(self):
         """Called by the fused optimizer after it rewrote the master weights and the bf16 shadow in one kernel."""
         # (that kernel refreshes only the hi half: the fp32 parity mode splits again at the next forward)
         self._shadow_version = self.flat_param._version if self.flat_shadow_lo is None else -1
+        self._shadow_epoch += 1
+
+    def _dgrad_weights_t(self):
+        """Transposed bf16 copies [in_features][hidden] of every layer's o_proj and down_proj weights, or None.
+        With hidden_size 512 the input gradients of those two projections (dx = dy @ W, reduction over the 512
+        outputs) run on the GEMM kernel that keeps a 256-token panel of dy in registers, which wants both operands
+        with the reduction index contiguous. Two batched transpose launches per optimizer step."""
+        cfg = self.cfg
+        if cfg.hidden_size != 512 or self.flat_shadow_lo is not None or cfg.arch != "llama":
+            return None
+        d, HD, I, L = cfg.hidden_size, cfg.num_attention_heads * cfg.head_dim, cfg.intermediate_size, \
+            cfg.num_hidden_layers
+        if self._wt is None:
+            self._wt = (torch.empty(L, HD, d, dtype=torch.bfloat16, device=self.flat_shadow.device),
+                        torch.empty(L, I, d, dtype=torch.bfloat16, device=self.flat_shadow.device))
+            self._wt_epoch = -1
+        if self._wt_epoch != self._shadow_epoch:
+            o0, o1 = (self._offsets[f"model.layers.{l}.self_attn.o_proj.weight"] for l in (0, min(1, L - 1)))
+            d0 = self._offsets["model.layers.0.mlp.down_proj.weight"]
+            stride = o1 - o0   # layers are laid out identically, one after the other
+            ops.transpose_bf16(self.flat_shadow[o0:], self._wt[0], d, HD, HD, d, L, stride, HD * d)
+            ops.transpose_bf16(self.flat_shadow[d0:], self._wt[1], d, I, I, d, L, stride, I * d)
+            self._wt_epoch = self._shadow_epoch
+        return self._wt
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
@@ -643,6 +671,7 @@ class MidiLM(GenerationMixin, nn.Module):
         datt = torch.empty(T, H * Dh, dtype=bf, device=dev)
         dqkv = torch.empty(T, NQ, dtype=bf, device=dev)
         delta = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+        wt = self._dgrad_weights_t() if (lo is None and not f32) else None
         for l in range(cfg.num_hidden_layers - 1, -1, -1):
             v = self._layers[l]
             h_in, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o, lts = saved[l]
@@ -651,6 +680,8 @@ class MidiLM(GenerationMixin, nn.Module):
             # ---- MLP branch
             if fused:
                 lo.bwd_fused(dh_lp, act, lts[3], v.s_down, la, "down", dact, I, d)
+            elif wt is not None:
+                ops.linear_dgrad_t(dh_lp, wt[1][l], dact)
             else:
                 ops.linear_dgrad(dh_lp, v.s_down, dact)
             if la is None:
@@ -675,6 +706,8 @@ class MidiLM(GenerationMixin, nn.Module):
             # ---- attention branch
             if fused:
                 lo.bwd_fused(dh_lp, att_o, lts[1], v.s_o, la, "o", datt, H * Dh, d)
+            elif wt is not None:
+                ops.linear_dgrad_t(dh_lp, wt[0][l], datt)
             else:
                 ops.linear_dgrad(dh_lp, v.s_o, datt)
             if la is None:

@@ -418,6 +418,18 @@ def cast(src, dst):
     call("mgen_cast", _p(src), _p(dst), src.numel(), kind, _stream())
 
 
+def transpose_bf16(src, dst, R, C, ldin, ldout, nbatch=1, bs_in=0, bs_out=0):
+    """dst[b] [C][R] = src[b] [R][C]^T (bf16), matrices bs_in / bs_out elements apart."""
+    call("mgen_transpose_bf16", _p(src), _p(dst), R, C, ldin, ldout, nbatch, bs_in, bs_out, _stream())
+
+
+def linear_dgrad_t(dy, w_t, dx):
+    """dx[T,K] = dy[T,N] @ w[N,K] given w_t = w^T stored [K][N] (the reduction index contiguous in both operands)."""
+    T, N = dy.shape
+    K = w_t.shape[0]
+    gemm(dy, w_t, dx, T, K, N, dy.stride(0), w_t.stride(0), dx.stride(0), False, False, OUT_BF16)
+
+
 def ce_count(labels, inv_count, count=None, ignore_index=-100, V=0, err_flag=None):
     """V > 0: labels outside [0, V) are not counted and set bit 2 of err_flag."""
     B, S = labels.shape

@@ -1,0 +1,145 @@
+"""The K = 512 GEMM kernel that keeps the token panel in registers (csrc/gemm_rs.hip), through the C-ABI:
+against torch fp32 arithmetic on the same bf16 inputs, bit for bit against the tile-loop kernel it replaces
+(MGEN_GEMM_RS=0 is read on every call), with padded leading dimensions, in the SwiGLU form, behind the transposed
+weight copies of the input-gradient products, and inside one training step of the default decoder."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mgen import ops as o
+    return o
+
+
+@pytest.fixture(autouse=True)
+def _rs_on():
+    os.environ.pop("MGEN_GEMM_RS", None)
+    yield
+    os.environ.pop("MGEN_GEMM_RS", None)
+
+
+def _both(run):
+    """Runs `run(out_tag)` with the register-panel kernel and with the tile-loop kernel."""
+    os.environ["MGEN_GEMM_RS"] = "1"
+    a = run()
+    os.environ["MGEN_GEMM_RS"] = "0"
+    b = run()
+    os.environ.pop("MGEN_GEMM_RS", None)
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize("M,N,pad", [(16384, 1024, 0), (16384, 1088, 8), (32768, 3072, 0), (16640, 1536, 64)])
+def test_plain_against_fp32_and_tile_loop(ops, M, N, pad):
+    K = 512
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K + pad, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    b = (torch.randn(N, K + pad, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    ldc = N + pad
+
+    def run():
+        c = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device=dev())
+        ops.gemm(a, b, c, M, N, K, a.stride(0), b.stride(0), ldc, False, False, ops.OUT_BF16)
+        return c
+
+    new, old = _both(run)
+    assert torch.equal(new, old), "register-panel kernel differs from the tile-loop kernel"
+    if pad:
+        assert bool((new[:, N:] == 7.0).all()), "wrote outside the N columns"
+    rows = torch.arange(0, M, 97, device=dev())   # a strided sample of rows against fp32 on the same inputs
+    ref = a[rows, :K].float() @ b[:, :K].float().t()
+    err = float((new[rows, :N].float() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, err
+
+
+def test_column_runs_when_rows_do_not_fill_the_chip(ops):
+    """Few row panels: the column range is cut into runs (one workgroup per panel and run); an odd number of column
+    pairs per run and the rotated block order are covered by 1088 columns over 4 runs."""
+    M, N, K = 16384, 2176, 512
+    g = torch.Generator().manual_seed(5)
+    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(dev())
+    b = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).to(dev())
+
+    def run():
+        c = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+        ops.gemm(a, b, c, M, N, K, K, K, N, False, False, ops.OUT_BF16)
+        return c
+
+    new, old = _both(run)
+    assert torch.equal(new, old)
+
+
+def test_swiglu_form(ops):
+    M, I, K = 16384, 1024, 512
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    w = (torch.randn(2 * I, K, generator=g) * 0.1).to(torch.bfloat16).to(dev())
+
+    def run():
+        gu = torch.zeros(M, 2 * I, dtype=torch.bfloat16, device=dev())
+        act = torch.zeros(M, I, dtype=torch.bfloat16, device=dev())
+        assert ops.linear_swiglu_fwd(x, w, gu, act)
+        return gu, act
+
+    (gu1, act1), (gu0, act0) = _both(run)
+    assert torch.equal(gu1, gu0) and torch.equal(act1, act0)
+    # and against the separate kernels' arithmetic in torch: silu in fp32 from the bf16 gate, rounded, times up
+    gf = gu1[:, :I].float()
+    ref = ((gf * torch.sigmoid(gf)).to(torch.bfloat16).float() * gu1[:, I:].float()).to(torch.bfloat16)
+    diff = (act1.float() - ref.float()).abs().max() / ref.float().abs().max()
+    assert float(diff) < 1e-2
+
+
+def test_transposed_weight_copies(ops):
+    L, R, C = 3, 512, 1024
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn(L, R * C + 64, generator=g).to(torch.bfloat16).to(dev())   # matrices 64 elements apart
+    dst = torch.zeros(L, C, R, dtype=torch.bfloat16, device=dev())
+    ops.transpose_bf16(src, dst, R, C, C, R, L, src.stride(0), C * R)
+    for l in range(L):
+        assert torch.equal(dst[l], src[l, :R * C].view(R, C).t())
+    # ragged sizes
+    s2 = torch.randn(70, 130, generator=g).to(torch.bfloat16).to(dev())
+    d2 = torch.zeros(130, 72, dtype=torch.bfloat16, device=dev())
+    ops.transpose_bf16(s2, d2, 70, 130, 130, 72)
+    assert torch.equal(d2[:, :70], s2.t()) and bool((d2[:, 70:] == 0).all())
+
+
+def test_training_step_identical_with_and_without(ops):
+    """Default decoder, 8 x 2048 tokens: the loss is bit-identical and every gradient equal up to the summation order
+    of the weight-gradient atomics whether the K = 512 products
+    (QKV, gate/up + SwiGLU, lm_head logits, o_proj / down_proj input gradients through the transposed copies) run on
+    the register-panel kernel or on the tile-loop kernel."""
+    from mgen import MidiLM
+    from mgen.config import default_decoder
+    cfg = default_decoder()
+    cfg.num_hidden_layers = 2
+    cfg.lm_head_chunk_tokens = 16384
+    model = MidiLM(cfg, device="cuda:0", seed=1)
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(3, cfg.vocab_size, (8, 2048), generator=g).to(dev())
+
+    def run():
+        model.zero_grad()
+        loss = model(input_ids=ids, labels=ids).loss
+        loss.backward()
+        return loss.detach().clone(), model.flat_grad.clone()
+
+    (l1, g1), (l0, g0) = _both(run)
+    assert torch.equal(l1, l0), (float(l1), float(l0))
+    # (the weight-gradient products add their K slices with fp32 atomics in arrival order: not bit-reproducible
+    # from run to run with either kernel)
+    err = float((g1 - g0).abs().max() / g0.abs().max())
+    assert err < 1e-5, err
+    assert model._wt is not None and model._wt_epoch == model._shadow_epoch
+    # initial loss of a randomly initialised decoder: ln V + d * 0.02^2 / 2 within a few percent
+    assert abs(float(l1) - 11.93) < 0.4
