@@ -19,7 +19,7 @@
 // The sixteen lanes that a ds_read_b128 serves together hold sixteen different values of r & 15, i.e. sixteen
 // different 16-byte bank groups. The LDS-DMA writes a row as one linear KiB, so the permutation is applied to each
 // lane's SOURCE address.
-#include "common.h"
+#include "lds_dma.h"
 #include "gemm_rs.h"
 #include <type_traits>
 
@@ -47,17 +47,6 @@ struct RsArgs {
     int xcd_map;          // grid is a multiple of 8: workgroups of one XCD share a run
 };
 
-// raw buffer descriptor over `bytes` bytes from p on (reads past the end return zeros)
-__device__ __forceinline__ u32x4 make_rsrc(const void* p, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)p;
-    u32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
-    r[2] = __builtin_amdgcn_readfirstlane(bytes);
-    r[3] = 0x00020000u;
-    return r;
-}
-
 // The wave's 8 rows (wave + 4 q + 16 half) of a 32-row block whose first row starts `soff` bytes into the buffer,
 // into the slot at LDS byte address `dst0` (+ 1024 * row). One asm statement: the compiler never learns that LDS
 // writes are pending, all waiting is done by hand with counted s_waitcnt vmcnt.
@@ -83,17 +72,6 @@ __device__ __forceinline__ void rs_issue(const u32x4& rsrc, const int (&voff)[4]
         : [dst] "s"(dst0), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [rs] "s"(rsrc),
           [st] "s"(step16)
         : "memory", "m0", "scc");
-}
-
-// one of those 8 rows as a statement of its own (piece q: row wave + 4 (q & 3) + 16 (q >> 2))
-__device__ __forceinline__ void rs_issue_piece(const u32x4& rsrc, int voff, unsigned dst, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 : : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
-}
-
-template <int N>
-__device__ __forceinline__ void rs_wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // SW: B = [gate rows; up rows] (2 I rows), C = [gate | up] and act = silu(gate) * up
@@ -124,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     const unsigned lds0 = lds_addr(smem);
     const int ldb2 = (int)(g.ldb * 2);
     const int brows = SW ? 2 * g.I : g.N;
-    const u32x4 rsB = make_rsrc(g.B, (unsigned)(((long)(brows - 1) * g.ldb + RS_K) * 2));
+    const u32x4 rsB = dma_rsrc(g.B, (unsigned)(((long)(brows - 1) * g.ldb + RS_K) * 2));
     int voffB[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -162,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     bf16x8 Af[2][RS_KS];
     {
         const int lda2 = (int)(g.lda * 2);
-        const u32x4 rsA = make_rsrc(g.A, (unsigned)(((long)(g.M - 1) * g.lda + RS_K) * 2));
+        const u32x4 rsA = dma_rsrc(g.A, (unsigned)(((long)(g.M - 1) * g.lda + RS_K) * 2));
         int voffA[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) voffA[q] = voffB[q] + (wave + 4 * q) * (lda2 - ldb2);
@@ -263,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
             // block before this one carried a pair's stores (nb == 1), those stores. Every wave's LDS reads of block
             // jl - 1 have returned (they fed MFMAs that are issued); past the barrier its slot takes block jl + 3.
             if (!(DBG & 32)) {
-                if (nb == 0) rs_wait_vm<8>();
-                else rs_wait_vm<8 + S>();
+                if (nb == 0) dma_wait<8>();
+                else dma_wait<8 + S>();
             }
             asm volatile("s_barrier" ::: "memory");
             const int nsoff = __builtin_amdgcn_readfirstlane(block_soff(jl + 3));
@@ -298,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
                 // piece q of block jl + 3 behind k-step 4 q + WV (the last one, 28 + WV, behind the block's last store)
                 if (!(DBG & 4) && (ks & 3) == WV) {
                     const int q = ks >> 2;
-                    rs_issue_piece(rsB, voffB[q & 3], ndst + 0x1000 * q, nsoff + (q >> 2) * 16 * ldb2);
+                    dma_piece(rsB, voffB[q & 3], ndst + 0x1000 * q, nsoff + (q >> 2) * 16 * ldb2);
                 }
                 if (out) {
                     if (ks < 8) park(nb ^ 1, ks);

@@ -143,3 +143,28 @@ def test_training_step_identical_with_and_without(ops):
     assert model._wt is not None and model._wt_epoch == model._shadow_epoch
     # initial loss of a randomly initialised decoder: ln V + d * 0.02^2 / 2 within a few percent
     assert abs(float(l1) - 11.93) < 0.4
+
+
+# ---------------------------------------------------------------- output-stationary weight-gradient kernel
+@pytest.mark.parametrize("M,N,K,acc", [(512, 1024, 4096, True), (3072, 512, 8192, True), (1000, 520, 4096, True),
+                                       (2048, 768, 2048, False), (9000, 512, 2080, True)])
+def test_weight_gradient_kernel(ops, M, N, K, acc):
+    """csrc/gemm_os.hip (both operands stored [reduction][output index], fp32 output, with and without reduction
+    slices, ragged tile edges) against fp32 arithmetic on the same bf16 inputs and against the tile-loop kernel."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(K, M, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    b = (torch.randn(K, N, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    ldc = N + 8
+    outs = []
+    for flag in ("1", "0"):
+        os.environ["MGEN_GEMM_OS"] = flag
+        c = torch.full((M, ldc), 3.0, dtype=torch.float32, device=dev())
+        ops.gemm(a, b, c, M, N, K, M, N, ldc, True, True, ops.OUT_F32_ACC if acc else ops.OUT_F32)
+        outs.append(c)
+    os.environ.pop("MGEN_GEMM_OS", None)
+    new, old = outs
+    assert bool((new[:, N:] == 3.0).all()), "wrote outside the N columns"
+    ref = a.float().t() @ b.float() + (3.0 if acc else 0.0)
+    scale = float(ref.abs().max())
+    assert float((new[:, :N] - ref).abs().max()) / scale < 2e-5
+    assert float((new[:, :N] - old[:, :N]).abs().max()) / scale < 2e-6

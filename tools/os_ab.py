@@ -1,0 +1,43 @@
+"""Output-stationary weight-gradient GEMM against the tile-loop kernel on the GPU box (MGEN_GEMM_OS=0 switches the
+new kernel off, read on every call): agreement up to the summation order, and timing."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
+import torch
+from mgen import ops
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+ok = True
+for name, M, N, K, acc in [("qkv wgrad", 3072, 512, 65536, True), ("gu wgrad", 4096, 512, 65536, True),
+                           ("o wgrad", 512, 1024, 65536, True), ("down wgrad", 512, 2048, 65536, True),
+                           ("lm wgrad 8k", 151936, 512, 8192, True), ("lm wgrad 32k", 151936, 512, 32768, True),
+                           ("lm wgrad store", 151936, 512, 8192, False), ("ragged", 1000, 520, 4096, True)]:
+    a = (torch.randn(K, M, device=dev) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(K, N, device=dev) * 0.5).to(torch.bfloat16)
+    outs, ts = [], []
+    for flag in ("0", "1"):
+        os.environ["MGEN_GEMM_OS"] = flag
+        c = torch.full((M, N), 1.0, dtype=torch.float32, device=dev)
+        run = lambda: ops.gemm(a, b, c, M, N, K, M, N, N, True, True, ops.OUT_F32_ACC if acc else ops.OUT_F32)
+        run(); torch.cuda.synchronize()
+        outs.append(c.clone())
+        ts.append(timeit(run))
+    err = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
+    fl = 2.0 * M * N * K
+    good = err < 2e-6
+    ok &= good
+    print(f"{name:16s} M={M:6d} N={N:5d} K={K:6d}: old {ts[0]:8.1f} us ({fl/ts[0]/1e6:7.1f} TF/s)  new {ts[1]:8.1f} us "
+          f"({fl/ts[1]/1e6:7.1f} TF/s)  rel diff {err:.1e} {'ok' if good else 'BAD'}", flush=True)
+print("ALL OK" if ok else "MISMATCH")
+sys.exit(0 if ok else 1)
