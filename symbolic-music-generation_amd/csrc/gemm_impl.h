@@ -625,11 +625,11 @@ static int gemm_impl(const void* A, const void* B, void* C, const void* resid, c
         K += K2;   // from here on: the total reduction length
     }
 #if !MGEN_GEMM_SEG
-    // weight gradients (both operands stored with the reduction index as the row index, fp32 output, long reduction):
-    // the output-stationary kernel (gemm_os.hip)
-    if (transA && transB && (out_mode == OUT_F32_ACC || out_mode == OUT_F32) && !bias && !second && alpha == 1.0f &&
-        slabs <= 1 && mgen_gemm_os_fits(M, N, K, lda, ldb, ldc))
-        return mgen_gemm_os_launch(A, B, (float*)C, M, N, K, lda, ldb, ldc, out_mode == OUT_F32_ACC, stream);
+    // long reduction: weight gradients, and the input-gradient / residual-projection products with few output columns,
+    // on the output-stationary kernel (gemm_os.hip)
+    if (!bias && !second && alpha == 1.0f && slabs <= 1 &&
+        mgen_gemm_os_fits(M, N, K, lda, ldb, ldc, ldr, transA, transB, out_mode))
+        return mgen_gemm_os_launch(A, B, C, resid, M, N, K, lda, ldb, ldc, ldr, transA, transB, out_mode, stream);
     // short reduction, many rows, bf16 output: the kernel that keeps the row panel in registers (gemm_rs.hip)
     if (!transA && !transB && out_mode == OUT_BF16 && !bias && !second && alpha == 1.0f && slabs <= 1 &&
         mgen_gemm_rs_fits(M, N, K, lda, ldb, ldc))

@@ -1,43 +1,57 @@
-// bf16 GEMM for weight gradients: C[M,N] (fp32) (+)= A^T B with both operands stored with the reduction index as the
-// row index (A = dY [tokens][M], B = X [tokens][N]; reference: the grad_weight product of nn.Linear's backward,
-// grad_output^T @ input, as reached from transformers models/qwen3/modeling_qwen3.py:76-83,225-236).
+// Output-stationary bf16 GEMM for products with a long reduction: C[M,N] = op(A) op(B), fp32 accumulate.
 //
-// Output stationary: a workgroup of four waves (one per SIMD, 512 registers each) owns a 256 x 256 output tile, each
-// wave a 128 x 128 quarter in 256 accumulator registers, and streams its slice of the reduction range in steps of
-// 32 rows through a four-slot LDS ring filled by LDS-DMA: three steps of loads in flight, one barrier per step, the
-// 8 DMA pieces of a wave spread between its MFMAs, the waves' pieces at staggered positions. Because the contiguous
-// index of both operands is the OUTPUT index, a 32-row step still moves whole 256-byte row segments. Operand
-// fragments are read with the transposing LDS read from the same swizzled image the other GEMM kernels use.
-// Few output tiles and a long reduction (layer weights): the reduction range is cut into slices, one workgroup per
-// tile and slice, added with fp32 atomics. Many tiles (lm_head): one workgroup per tile.
+// Serves the backward products of the linear layers and the two residual projections (reference: nn.Linear forward
+// and its autograd backward as reached from transformers models/qwen3/modeling_qwen3.py:76-83,225-236):
+//   weight gradients   dW = dY^T X      both operands stored [reduction][output index], fp32 output added in place
+//   input gradients    dX = dY W        A rows reduction-contiguous, B stored [reduction][output index], bf16 output
+//   o_proj / down_proj y = x W^T + res  both operands reduction-contiguous, fp32 output = residual + bf16(product)
+//
+// A workgroup of four waves (one per SIMD, 512 registers each) owns a 256 x 256 output tile, each wave a 128 x 128
+// quarter in 256 accumulator registers, and streams the reduction range in steps of 32 through a four-slot LDS ring
+// filled by LDS-DMA: each wave fills one of a step's four 8 KiB images (A rows 0..127 | A 128..255 | B 0..127 |
+// B 128..255), three steps of loads in flight, one barrier per step, a wave's 8 DMA pieces spread between its MFMAs
+// and the four waves' pieces at staggered positions. A step is waited for one barrier early, so the first fragments
+// of the next step are requested before the barrier that opens it.
+//
+// Images. An operand stored [reduction][output index] keeps whole 256-byte row segments per step (32 rows x 256
+// bytes, the IMG256 swizzle of common.h) and is read with the transposing LDS read. A reduction-contiguous operand
+// contributes 128 rows x 64 bytes per image; 16-byte chunk c of row r sits at position c ^ ((r >> 2) & 3), which
+// spreads the sixteen lanes a ds_read_b128 serves together over all banks.
+//
+// Few output tiles and a long reduction (layer weight gradients): the reduction range is cut into slices, one
+// workgroup per tile and slice, added with fp32 atomics. Otherwise one workgroup per tile.
 #include "lds_dma.h"
 #include "gemm_os.h"
-#include <type_traits>
 
 namespace {
 
 constexpr int OS_BK = 32;
-constexpr int OS_IMG = OS_BK * 256;          // 32 reduction rows x 128 columns: 8 KiB
-constexpr int OS_SLOT = 4 * OS_IMG;          // A columns 0..127 | A 128..255 | B 0..127 | B 128..255
+constexpr int OS_IMG = 8192;                 // one image of one step
+constexpr int OS_SLOT = 4 * OS_IMG;
 constexpr int OS_NSLOT = 4;
 constexpr int OS_LDS = OS_NSLOT * OS_SLOT;   // 128 KiB
+
+enum { OS_OUT_BF16 = 0, OS_OUT_F32 = 1, OS_OUT_F32_ACC = 2, OS_OUT_RESID_ROUND = 3, OS_OUT_RESID = 4 };
 
 struct OsArgs {
     const bf16* A;
     const bf16* B;
-    float* C;
-    long lda, ldb, ldc;
+    void* C;
+    const float* R;
+    long lda, ldb, ldc, ldr;
     int M, N, K;
     int nbm, nbn;
-    int splitk, kper;   // reduction slices of kper rows (a multiple of OS_BK)
-    int accumulate;
+    int splitk, kper;   // reduction slices of kper indices (a multiple of OS_BK)
 };
 
-template <int WV>
+// AKM / BKM: the operand is stored [reduction][output index] (else [output index][reduction])
+template <bool AKM, bool BKM, int OUT, int WV>
 __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, int wave) {
+    constexpr bool ROWMAJOR_OUT = OUT != OS_OUT_F32 && OUT != OS_OUT_F32_ACC;
     const int nt = g.nbm * g.nbn;
     const int wid = xcd_remap(blockIdx.x, nt * g.splitk);
-    // slice-major: the tiles of one reduction slice are neighbours and share that slice of both operands in L2
+    // slice-major: the tiles of one reduction slice are neighbours and share that slice of both operands in L2;
+    // tiles of one tile row (same A rows) are neighbours too
     const int kslice = wid / nt, t = wid % nt;
     const int tm = t / g.nbn, tn = t % g.nbn;
     const int m0 = tm * 256, n0 = tn * 256;
@@ -47,23 +61,40 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
     if (nslot <= 0) return;
     const unsigned lds0 = lds_addr(smem);
 
-    // ---- loader role: this wave fills one of the four images of every slot (8 pieces of 4 rows x 256 bytes)
+    // ---- loader role: this wave fills one of the four images of every step with 8 one-KiB pieces. The buffer
+    // descriptor starts at the image's first element of this workgroup's slice, so offsets stay far below 4 GiB.
     const bool isB = wave >= 2;
-    const bf16* P = isB ? g.B : g.A;
+    const bool km = isB ? BKM : AKM;
     const int ld2 = (int)((isB ? g.ldb : g.lda) * 2);
+    const int o0 = isB ? n0 + 128 * (wave - 2) : m0 + 128 * wave;    // first output index of the image
     const int extent = isB ? g.N : g.M;
-    const int col0 = isB ? n0 + 128 * (wave - 2) : m0 + 128 * wave;
-    const u32x4 rs = dma_rsrc(P, (unsigned)(((long)(g.K - 1) * (ld2 / 2) + extent) * 2));
+    const bf16* base = (isB ? g.B : g.A) + (km ? (long)kbeg * (ld2 / 2) + o0 : (long)o0 * (ld2 / 2) + kbeg);
+    // valid bytes from base on: whole rows up to the operand's last row, the last one only up to its last element
+    const long rows_left = km ? (long)(g.K - kbeg) : (long)(extent - o0);
+    const long last_len = km ? (long)(extent - o0) : (long)(g.K - kbeg);
+    const long span = rows_left > 0 ? ((rows_left - 1) * (ld2 / 2) + last_len) * 2 : 0;
+    const u32x4 rs = dma_rsrc(base, (unsigned)(span > 0xFFFFFFFFL ? 0xFFFFFFFFL : (span > 0 ? span : 0)));
     int voff[4];
+    int pstep;   // buffer offset between a wave's consecutive pieces of the same voff
+    if (km) {
+        // piece pc: reduction rows 4 pc .. 4 pc + 3, 256 bytes each (IMG256 swizzle on the source chunk)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int kr = 4 * q + (lane >> 4);
-        voff[q] = kr * ld2 + col0 * 2 + 16 * ((lane & 15) ^ swz256(kr));
+        for (int q = 0; q < 4; ++q) {
+            const int kr = 4 * q + (lane >> 4);
+            voff[q] = kr * ld2 + 16 * ((lane & 15) ^ swz256(kr));
+        }
+        pstep = 16 * ld2;
+    } else {
+        // piece pc: output rows 16 pc .. 16 pc + 15, 64 bytes each; the chunk swizzle does not depend on pc
+        const int v = (lane >> 2) * ld2 + 16 * ((lane & 3) ^ ((lane >> 4) & 3));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) voff[q] = v + 16 * q * ld2;
+        pstep = 64 * ld2;
     }
-    // piece pc (0..7) of the slot whose first row is k0: rows 4 pc .. 4 pc + 3 (voff[pc & 3], + 16 rows for pc >= 4)
+    const int sstep = km ? OS_BK * ld2 : OS_BK * 2;   // buffer offset from one step to the next
     auto piece = [&](int sl, int pc) {
         const int sc = min(sl, nslot - 1);   // past the end: a harmless reload, so that the wait counts stay fixed
-        const int soff = __builtin_amdgcn_readfirstlane((kbeg + sc * OS_BK + 16 * (pc >> 2)) * ld2);
+        const int soff = __builtin_amdgcn_readfirstlane(sc * sstep + (pc >> 2) * pstep);
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (sl & 3) * OS_SLOT + wave * OS_IMG + pc * 1024);
         dma_piece(rs, voff[pc & 3], dst, soff);
     };
@@ -84,19 +115,27 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
         for (int pc = 0; pc < 8; ++pc) piece(sl, pc);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
+    // fragment of 32 output indices x 16 reduction indices (k-step ks of the slot) from an image
+    auto frag = [&](const char* img, bool kmaj, int ks, int o) -> bf16x8 {
+        if (kmaj) return frag_col_img256<false>(img, 16 * ks, 32 * o, lane);
+        const int row = 32 * o + (lane & 31);
+        return lds_read_b128(img, row * 64 + 16 * ((2 * ks + (lane >> 5)) ^ ((row >> 2) & 3)));
+    };
     auto frags = [&](const char* slot, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = frag_col_img256<false>(slot + wm * OS_IMG, 16 * ks, 32 * i, lane);
+        for (int i = 0; i < 4; ++i) fa[i] = frag(slot + wm * OS_IMG, AKM, ks, i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = frag_col_img256<false>(slot + (2 + wn) * OS_IMG, 16 * ks, 32 * j, lane);
+        for (int j = 0; j < 4; ++j) fb[j] = frag(slot + (2 + wn) * OS_IMG, BKM, ks, j);
     };
-    // 16 MFMAs of one 16-deep step; DMA piece pc0 + (idx >> 2) of slot `nsl` behind MFMA idx with idx & 3 == WV
+    // 16 MFMAs of one 16-deep step; DMA piece pc0 + (idx >> 2) of step `nsl` behind MFMA idx with idx & 3 == WV.
+    // Weight gradients: D[row = m][col = n], a register = 32 consecutive n of two rows (atomics by row segments).
+    // Row-major outputs: D[row = n][col = m], a lane = one row m and groups of 4 consecutive n.
     auto step = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], int nsl, int pc0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[i][j] = mfma32(fa[i], fb[j], acc[i][j]);   // D[row = m][col = n]: a register = 32 consecutive n
+                acc[i][j] = ROWMAJOR_OUT ? mfma32(fb[j], fa[i], acc[i][j]) : mfma32(fa[i], fb[j], acc[i][j]);
                 if (((4 * i + j) & 3) == WV) piece(nsl, pc0 + ((4 * i + j) >> 2));
             }
     };
@@ -104,11 +143,17 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
     bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
     frags(smem, 0, fa0, fb0);
     for (int s = 0; s < nslot; ++s) {
-        // This wave's pieces of slot s + 1 have landed (younger: the 8 pieces of slot s + 2). Every wave's LDS reads of
-        // slot s - 1 have returned (they fed MFMAs that are issued); past the barrier its ring slot takes slot s + 3,
-        // and slot s + 1 is complete for every wave: its first fragments may be requested during this step.
+        // This wave's pieces of step s + 1 have landed (younger: the 8 pieces of step s + 2). Every wave's LDS reads of
+        // step s - 1 have returned (they fed MFMAs that are issued); past the barrier its ring slot takes step s + 3,
+        // and step s + 1 is complete for every wave: its first fragments may be requested during this step.
         dma_wait<8>();
         asm volatile("s_barrier" ::: "memory");
+        // the accumulators live in the accumulator half of the register file (some instances would otherwise be
+        // given vector registers for them and spill everything else)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
         const char* cur = smem + (s & 3) * OS_SLOT;
         const char* nxt = smem + ((s + 1) & 3) * OS_SLOT;
         frags(cur, 1, fa1, fb1);
@@ -116,63 +161,158 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
         frags(nxt, 0, fa0, fb0);
         step(fa1, fb1, s + 3, 4);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be pending when the wave ends
+    // no LDS-DMA may be pending when the wave ends; the row-major outputs reuse the ring as a staging area once every
+    // wave has left the loop
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    // ---- output: one accumulator register = 32 consecutive columns of two rows (two 128-byte segments)
+    // the output addresses are derived from a lane index the compiler cannot trace back past the loop: it would
+    // otherwise compute them in front of the loop and carry (or spill) them through it
+    asm volatile("" : "+v"(lane));
+    const int h = lane >> 5, r = lane & 31;
+    if constexpr (!ROWMAJOR_OUT) {
+        float* C = reinterpret_cast<float*>(g.C);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + 128 * wn + 32 * j + (lane & 31);
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + 128 * wn + 32 * j + r;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 128 * wm + 32 * i + acc_row(r, lane);
-                if (m < g.M && n < g.N) {
-                    float* c = g.C + (long)m * g.ldc + n;
-                    if (g.accumulate) atomicAdd(c, acc[i][j][r]);
-                    else *c = acc[i][j][r];
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + 128 * wm + 32 * i + acc_row(e, lane);
+                    if (m < g.M && n < g.N) {
+                        float* c = C + (long)m * g.ldc + n;
+                        if (OUT == OS_OUT_F32_ACC) atomicAdd(c, acc[i][j][e]);
+                        else *c = acc[i][j][e];
+                    }
                 }
             }
+    } else {
+        // Row-major outputs: the wave's quarter goes through its 32 KiB of the ring as fp32, 64 rows x 512 bytes at a
+        // time (16-byte chunks swizzled by row), and is read back as whole row segments. bf16 output: rounded on the
+        // way out, 16 bytes per lane; fp32 output = residual + (bf16-rounded) product.
+        char* st = smem + wave * 32768;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int row = 32 * i2 + r, ch = 8 * j + 2 * g4 + h;   // 16-byte chunk = 4 floats
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[2 * half + i2][j][4 * g4 + e];
+                        *reinterpret_cast<f32x4*>(st + row * 512 + ((ch ^ (row & 31)) << 4)) = o;
+                    }
+            if constexpr (OUT == OS_OUT_BF16) {
+                bf16* C = reinterpret_cast<bf16*>(g.C);
+#pragma unroll 4
+                for (int it = 0; it < 16; ++it) {
+                    const int row = it * 4 + (lane >> 4), c8 = lane & 15;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + row * 512 + (((2 * c8) ^ (row & 31)) << 4));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + row * 512 + (((2 * c8 + 1) ^ (row & 31)) << 4));
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (bf16)v0[e]; o[4 + e] = (bf16)v1[e]; }
+                    const int m = m0 + 128 * wm + 64 * half + row, n = n0 + 128 * wn + c8 * 8;
+                    if (m < g.M && n < g.N) *reinterpret_cast<bf16x8*>(C + (long)m * g.ldc + n) = o;
+                }
+            } else {
+                float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll 8
+                for (int it = 0; it < 32; ++it) {
+                    const int row = it * 2 + (lane >> 5), ch = lane & 31;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(st + row * 512 + ((ch ^ (row & 31)) << 4));
+                    const int m = m0 + 128 * wm + 64 * half + row, n = n0 + 128 * wn + ch * 4;
+                    if (m < g.M && n < g.N) {
+                        const f32x4 res = *reinterpret_cast<const f32x4*>(g.R + (long)m * g.ldr + n);
+                        if (OUT == OS_OUT_RESID_ROUND) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = round_bf(v[e]);
+                        }
+                        v += res;
+                        *reinterpret_cast<f32x4*>(C + (long)m * g.ldc + n) = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the first half has been read out
         }
+    }
 }
 
+template <bool AKM, bool BKM, int OUT>
 __global__ __launch_bounds__(256, 1) void gemm_os_kernel(OsArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // four copies of the loop that differ only in where the wave's DMA pieces sit between its MFMAs
     switch (wave) {
-        case 0: os_body<0>(g, smem, lane, wave); break;
-        case 1: os_body<1>(g, smem, lane, wave); break;
-        case 2: os_body<2>(g, smem, lane, wave); break;
-        default: os_body<3>(g, smem, lane, wave); break;
+        case 0: os_body<AKM, BKM, OUT, 0>(g, smem, lane, wave); break;
+        case 1: os_body<AKM, BKM, OUT, 1>(g, smem, lane, wave); break;
+        case 2: os_body<AKM, BKM, OUT, 2>(g, smem, lane, wave); break;
+        default: os_body<AKM, BKM, OUT, 3>(g, smem, lane, wave); break;
     }
+}
+
+template <bool AKM, bool BKM, int OUT>
+int os_launch(const OsArgs& g, hipStream_t stream) {
+    static bool asked[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!asked[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_os_kernel<AKM, BKM, OUT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, OS_LDS);
+        if (e != hipSuccess) {
+            mgen_set_error("mgen_gemm_bf16: cannot reserve %d bytes of LDS: %s", OS_LDS, hipGetErrorString(e));
+            return MGEN_ELAUNCH;
+        }
+        asked[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_os_kernel<AKM, BKM, OUT>), dim3(g.nbm * g.nbn * g.splitk), dim3(256), OS_LDS, stream, g);
+    return mgen_check_launch("mgen_gemm_bf16");
 }
 
 }  // namespace
 
-bool mgen_gemm_os_fits(int M, int N, int K, long lda, long ldb, long ldc) {
+bool mgen_gemm_os_fits(int M, int N, int K, long lda, long ldb, long ldc, long ldr, int transA, int transB,
+                       int out_mode) {
     const char* e = getenv("MGEN_GEMM_OS");   // MGEN_GEMM_OS=0: never (same-process A/B runs)
     if (e && e[0] == '0') return false;
-    if (K % OS_BK != 0 || K < 2048 || M < 256 || N < 256 || (M % 8) || (N % 8) || (lda % 8) || (ldb % 8)) return false;
-    // byte offsets inside the buffer descriptors are 32-bit
-    if ((long)K * lda * 2 >= (1L << 32) || (long)K * ldb * 2 >= (1L << 32)) return false;
+    if (K % OS_BK != 0 || K < 1024 || M < 256 || N < 256 || (lda % 8) || (ldb % 8)) return false;
+    const bool wgrad = transA && transB && (out_mode == OS_OUT_F32_ACC || out_mode == OS_OUT_F32);
+    const bool dgrad = !transA && transB && out_mode == OS_OUT_BF16;
+    const bool proj = !transA && !transB && (out_mode == OS_OUT_RESID_ROUND || out_mode == OS_OUT_RESID);
+    // (the residual projections, both operands reduction-contiguous, measured 10-20 % slower here than on the
+    // tile-loop kernel: their 64-byte row pieces double the number of cache-line requests; MGEN_GEMM_OS=2 routes them)
+    if (!(wgrad || dgrad || (proj && e && e[0] == '2'))) return false;
+    if (wgrad) {
+        if (K < 2048 || (M % 8) || (N % 8)) return false;
+        // buffer offsets are 32-bit: one workgroup's reduction slice of either operand
+        if ((long)K * lda * 2 >= (1L << 32) || (long)K * ldb * 2 >= (1L << 32)) return false;
+        return true;
+    }
+    // the products with few output columns: whole 256-row tiles (rows beyond the operand would be read), at least as
+    // many tiles as CUs
+    if (M % 256 != 0 || N % 256 != 0 || N > 1024 || (long)(M / 256) * (N / 256) < 256) return false;
+    if ((ldc % 8) || (proj && ((ldc % 4) || (ldr % 4)))) return false;
+    if (256L * lda * 2 >= (1L << 32)) return false;
+    if (dgrad ? (long)K * ldb * 2 >= (1L << 32) : 256L * ldb * 2 >= (1L << 32)) return false;
     return true;
 }
 
-int mgen_gemm_os_launch(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc,
-                        int accumulate, hipStream_t stream) {
+int mgen_gemm_os_launch(const void* A, const void* B, void* C, const void* resid, int M, int N, int K, long lda,
+                        long ldb, long ldc, long ldr, int transA, int transB, int out_mode, hipStream_t stream) {
     OsArgs g;
-    g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C;
-    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.A = (const bf16*)A; g.B = (const bf16*)B; g.C = C; g.R = (const float*)resid;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr; g.M = M; g.N = N; g.K = K;
     g.nbm = (M + 255) / 256; g.nbn = (N + 255) / 256;
-    g.accumulate = accumulate;
     // one round of workgroups on 256 CUs: cut the reduction range while the tiles alone do not fill the chip
-    // (slices of at least 1024 rows; a product that does not accumulate cannot be cut)
+    // (slices of at least 1024 indices; only a product that is added to its output can be cut)
     const int tiles = g.nbm * g.nbn;
     const int steps = K / OS_BK;
     int sk = 1;
-    if (accumulate && tiles < 256) {
+    if (out_mode == OS_OUT_F32_ACC && tiles < 256) {
         sk = 256 / tiles;
         const int maxsk = steps / 32;
         if (sk > maxsk) sk = maxsk;
@@ -181,18 +321,10 @@ int mgen_gemm_os_launch(const void* A, const void* B, float* C, int M, int N, in
     const int per = (steps + sk - 1) / sk;
     g.kper = per * OS_BK;
     g.splitk = (steps + per - 1) / per;
-    static bool asked[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (!asked[dev]) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_os_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, OS_LDS);
-        if (e != hipSuccess) {
-            mgen_set_error("mgen_gemm_bf16: cannot reserve %d bytes of LDS: %s", OS_LDS, hipGetErrorString(e));
-            return MGEN_ELAUNCH;
-        }
-        asked[dev] = true;
-    }
-    hipLaunchKernelGGL(gemm_os_kernel, dim3(tiles * g.splitk), dim3(256), OS_LDS, stream, g);
-    return mgen_check_launch("mgen_gemm_bf16");
+    if (transA && transB)
+        return out_mode == OS_OUT_F32_ACC ? os_launch<true, true, OS_OUT_F32_ACC>(g, stream)
+                                          : os_launch<true, true, OS_OUT_F32>(g, stream);
+    if (transB) return os_launch<false, true, OS_OUT_BF16>(g, stream);
+    return out_mode == OS_OUT_RESID_ROUND ? os_launch<false, false, OS_OUT_RESID_ROUND>(g, stream)
+                                          : os_launch<false, false, OS_OUT_RESID>(g, stream);
 }

@@ -168,3 +168,32 @@ def test_weight_gradient_kernel(ops, M, N, K, acc):
     scale = float(ref.abs().max())
     assert float((new[:, :N] - ref).abs().max()) / scale < 2e-5
     assert float((new[:, :N] - old[:, :N]).abs().max()) / scale < 2e-6
+
+
+@pytest.mark.parametrize("kind", ["dgrad", "proj"])
+def test_output_stationary_row_major_outputs(ops, kind):
+    """Input-gradient form (A reduction-contiguous, B stored [K][N], bf16 output) and residual-projection form (both
+    operands reduction-contiguous, fp32 = residual + bf16(product)) of csrc/gemm_os.hip: bit for bit against the
+    tile-loop kernel and against fp32 arithmetic."""
+    M, N, K = 65536, 512, 1024
+    g = torch.Generator().manual_seed(21)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    if kind == "dgrad":
+        b = (torch.randn(K, N, generator=g) * 0.1).to(torch.bfloat16).to(dev())
+        res, mode, tb, dt = None, ops.OUT_BF16, True, torch.bfloat16
+    else:
+        b = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).to(dev())
+        res, mode, tb, dt = torch.randn(M, N, generator=g).to(dev()), ops.OUT_F32_RESID_BF16ROUND, False, torch.float32
+    outs = []
+    for flag in ("2", "0"):   # 2: also the residual projections, which are not routed to this kernel by default
+        os.environ["MGEN_GEMM_OS"] = flag
+        c = torch.zeros(M, N, dtype=dt, device=dev())
+        ops.gemm(a, b, c, M, N, K, K, b.stride(0), N, False, tb, mode, res, N if res is not None else 0)
+        outs.append(c)
+    os.environ.pop("MGEN_GEMM_OS", None)
+    assert torch.equal(outs[0], outs[1])
+    rows = torch.arange(0, M, 509, device=dev())
+    prod = a[rows].float() @ (b.float() if tb else b.float().t())
+    ref = prod if res is None else prod.to(torch.bfloat16).float() + res[rows]
+    err = float((outs[0][rows].float() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, err
