@@ -189,8 +189,9 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     tokens_per_s = world * B * S * args.steps / dt
 
-    # ---- roofline of the dominant kernel: the bf16 MFMA GEMM (x @ W^T form, bf16 out) that carries the QKV, gate-up
-    # and lm_head products. One extra step with a HIP event pair around every launch of that kernel on its stream.
+    # ---- roofline of the dominant kernel: the bf16 MFMA GEMM for x @ W^T products with a 512-long reduction and a
+    # bf16 output (QKV, lm_head logits, o_proj / down_proj input gradients through the transposed weight copies).
+    # One extra step with a HIP event pair around every launch of that kernel on its stream.
     roofline = None
     if True:  # every rank runs the extra step (it contains collectives for N > 1); rank 0 reports
         recs = []
@@ -221,8 +222,9 @@ def main():
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
         if (B, S) == (32, 2048) and args.model == "default" and os.path.exists(pmc):
             with open(pmc) as fh:
-                traffic = json.load(fh).get("gemm_fwd_bf16_avg_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel<TA=0,TB=0,OUT_BF16> (QKV, gate-up, lm_head forward)",
+                traffic = json.load(fh).get("roofline_kernel_avg_bytes_per_launch")
+        roofline = {"bound": "mfma", "kernel": "gemm_rs_kernel<false, 0> (bf16 products with a 512-long reduction: QKV, lm_head logits, "
+                              "o_proj / down_proj input gradients)",
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (PMC, profiles/r02_pmc_traffic.json); algorithmic: "

@@ -241,6 +241,192 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Input-gradient form with whole cache lines on both sides: A rows reduction-contiguous, B stored [reduction][output
+// index], bf16 output. A 32-deep step of a reduction-contiguous operand is only 64 bytes of every row - half a cache
+// line per request. Here the A images cover TWO steps (128 rows x 128 bytes, the IMG128 layout of common.h) in a ring
+// of three per row half, filled by waves 0 and 1 with 16 one-KiB pieces (8 rows x 128 bytes) during every even step;
+// the B images stay one step deep in a ring of four, filled by waves 2 and 3 with 8 pieces per step. 160 KiB of LDS.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KC_DIMG = 16384;                       // 128 rows x 64 reduction indices
+constexpr int KC_AREGION = 2 * 3 * KC_DIMG;          // [row half][ring of 3]
+constexpr int KC_BSLOT = 2 * OS_IMG;                 // B columns 0..127 | 128..255 of one step
+constexpr int KC_LDS = KC_AREGION + 4 * KC_BSLOT;    // 160 KiB
+
+template <int WV>
+__device__ __forceinline__ void os_body_kc(const OsArgs& g, char* smem, int lane, int wave) {
+    constexpr bool LOADS_A = WV < 2;
+    const int nt = g.nbm * g.nbn;
+    const int t = xcd_remap(blockIdx.x, nt);
+    const int tm = t / g.nbn, tn = t % g.nbn;
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int ndbl = g.K / 64;
+    const unsigned lds0 = lds_addr(smem);
+
+    // ---- loader role
+    const int ld2 = (int)((LOADS_A ? g.lda : g.ldb) * 2);
+    u32x4 rs;
+    int voff[4];
+    if (LOADS_A) {
+        const int o0 = m0 + 128 * wave;
+        rs = dma_rsrc(g.A + (long)o0 * g.lda, (unsigned)((127L * g.lda + g.K) * 2));
+        // piece p (0..15): rows 8 p .. 8 p + 7; the chunk swizzle (row >> 1) & 7 = 4 (p & 1) + (lane >> 4)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            voff[q] = (8 * q + (lane >> 3)) * ld2 + 16 * ((lane & 7) ^ (4 * q + (lane >> 4)));
+        voff[2] = voff[3] = 0;
+    } else {
+        const int o0 = n0 + 128 * (wave - 2);
+        rs = dma_rsrc(g.B + o0, (unsigned)(((long)(g.K - 1) * g.ldb + (g.N - o0)) * 2));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kr = 4 * q + (lane >> 4);
+            voff[q] = kr * ld2 + 16 * ((lane & 15) ^ swz256(kr));
+        }
+    }
+    // A: piece p of the double step ds into ring buffer ds % 3 (the caller passes the buffer)
+    auto piece_a = [&](int ds, int buf, int p) {
+        const int dc = min(ds, ndbl - 1);   // past the end: a harmless reload, so that the wait counts stay fixed
+        const int soff = __builtin_amdgcn_readfirstlane(dc * 128 + (p >> 1) * 16 * ld2);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (wave * 3 + buf) * KC_DIMG + p * 1024);
+        dma_piece(rs, voff[p & 1], dst, soff);
+    };
+    // B: piece pc (0..7) of step sl into ring slot sl & 3
+    auto piece_b = [&](int sl, int pc) {
+        const int sc = min(sl, 2 * ndbl - 1);
+        const int soff = __builtin_amdgcn_readfirstlane((sc * OS_BK + 16 * (pc >> 2)) * ld2);
+        const unsigned dst =
+            __builtin_amdgcn_readfirstlane(lds0 + KC_AREGION + (sl & 3) * KC_BSLOT + (wave - 2) * OS_IMG + pc * 1024);
+        dma_piece(rs, voff[pc & 3], dst, soff);
+    };
+
+    // ---- compute role
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (LOADS_A) {
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) piece_a(ds, ds, p);
+    } else {
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) piece_b(sl, pc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const char* abase = smem + wm * 3 * KC_DIMG;
+    const char* bbase = smem + KC_AREGION + wn * OS_IMG;
+    // fragments of k-step kq (0..3) of the double image in ring buffer buf / of k-step ks (0, 1) of B slot sl
+    auto frags = [&](int buf, int kq, int sl, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = frag_row_img128(abase + buf * KC_DIMG, 32 * i, kq, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = frag_col_img256<false>(bbase + (sl & 3) * KC_BSLOT, 16 * ks, 32 * j, lane);
+    };
+    // 16 MFMAs (D[row = n][col = m]); this wave's DMA pieces between them: an A loader issues 8 of the 16 pieces of
+    // double step `ads` per call during even steps (behind every other MFMA), a B loader 4 of the 8 pieces of step
+    // `bsl` per call in every step (behind every fourth)
+    auto step = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], bool even, int call, int ads, int abuf, int bsl) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = mfma32(fb[j], fa[i], acc[i][j]);
+                const int idx = 4 * i + j;
+                if (LOADS_A) {
+                    if (even && (idx & 1) == (WV & 1)) piece_a(ads, abuf, 8 * call + (idx >> 1));
+                } else {
+                    if ((idx & 3) == WV) piece_b(bsl, 4 * call + (idx >> 2));
+                }
+            }
+    };
+
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    frags(0, 0, 0, 0, fa0, fb0);
+    int bc = 0, bn = 1, bi = 2;   // ring buffers of the double steps d, d + 1, d + 2
+    for (int d = 0; d < ndbl; ++d) {
+        const int s = 2 * d;
+        // Even step 2 d. A loaders: younger than what must have landed are the 16 pieces of double step d + 1; B
+        // loaders: the 8 pieces of step s + 2. Everything a wave may read before the next barrier (the rest of this
+        // step and the first fragments of step s + 1) was complete for every wave at the last barrier.
+        if (LOADS_A) dma_wait<16>(); else dma_wait<8>();
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+        frags(bc, 1, s, 1, fa1, fb1);
+        step(fa0, fb0, true, 0, d + 2, bi, s + 3);
+        frags(bc, 2, s + 1, 0, fa0, fb0);
+        step(fa1, fb1, true, 1, d + 2, bi, s + 3);
+        // Odd step 2 d + 1: double step d + 1 (issued during step 2 d - 2) must be complete before this barrier, the
+        // 16 pieces of double step d + 2 are younger
+        if (LOADS_A) dma_wait<16>(); else dma_wait<8>();
+        asm volatile("s_barrier" ::: "memory");
+        frags(bc, 3, s + 1, 1, fa1, fb1);
+        step(fa0, fb0, false, 0, 0, 0, s + 4);
+        frags(bn, 0, s + 2, 0, fa0, fb0);
+        step(fa1, fb1, false, 1, 0, 0, s + 4);
+        const int tmp = bc; bc = bn; bn = bi; bi = tmp;
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- bf16 output through the wave's 32 KiB: fp32 quarter-tile halves of 64 rows x 512 bytes, rounded on the
+    // way out, whole 256-byte row segments
+    asm volatile("" : "+v"(lane));
+    const int h = lane >> 5, r = lane & 31;
+    char* st = smem + wave * 32768;
+    bf16* C = reinterpret_cast<bf16*>(g.C);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int row = 32 * i2 + r, ch = 8 * j + 2 * g4 + h;
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[2 * half + i2][j][4 * g4 + e];
+                    *reinterpret_cast<f32x4*>(st + row * 512 + ((ch ^ (row & 31)) << 4)) = o;
+                }
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4), c8 = lane & 15;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(st + row * 512 + (((2 * c8) ^ (row & 31)) << 4));
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(st + row * 512 + (((2 * c8 + 1) ^ (row & 31)) << 4));
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (bf16)v0[e]; o[4 + e] = (bf16)v1[e]; }
+            const int m = m0 + 128 * wm + 64 * half + row, n = n0 + 128 * wn + c8 * 8;
+            if (m < g.M && n < g.N) *reinterpret_cast<bf16x8*>(C + (long)m * g.ldc + n) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_os_kc_kernel(OsArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {
+        case 0: os_body_kc<0>(g, smem, lane, wave); break;
+        case 1: os_body_kc<1>(g, smem, lane, wave); break;
+        case 2: os_body_kc<2>(g, smem, lane, wave); break;
+        default: os_body_kc<3>(g, smem, lane, wave); break;
+    }
+}
+
 template <bool AKM, bool BKM, int OUT>
 __global__ __launch_bounds__(256, 1) void gemm_os_kernel(OsArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -285,7 +471,8 @@ bool mgen_gemm_os_fits(int M, int N, int K, long lda, long ldb, long ldc, long l
     const bool proj = !transA && !transB && (out_mode == OS_OUT_RESID_ROUND || out_mode == OS_OUT_RESID);
     // (the residual projections, both operands reduction-contiguous, measured 10-20 % slower here than on the
     // tile-loop kernel: their 64-byte row pieces double the number of cache-line requests; MGEN_GEMM_OS=2 routes them)
-    if (!(wgrad || dgrad || (proj && e && e[0] == '2'))) return false;
+    // (MGEN_GEMM_OS=4: weight gradients only, for same-box comparisons)
+    if (!(wgrad || (dgrad && !(e && e[0] == '4')) || (proj && e && e[0] == '2'))) return false;
     if (wgrad) {
         if (K < 2048 || (M % 8) || (N % 8)) return false;
         // buffer offsets are 32-bit: one workgroup's reduction slice of either operand
@@ -324,7 +511,24 @@ int mgen_gemm_os_launch(const void* A, const void* B, void* C, const void* resid
     if (transA && transB)
         return out_mode == OS_OUT_F32_ACC ? os_launch<true, true, OS_OUT_F32_ACC>(g, stream)
                                           : os_launch<true, true, OS_OUT_F32>(g, stream);
-    if (transB) return os_launch<false, true, OS_OUT_BF16>(g, stream);
+    if (transB) {
+        const char* e = getenv("MGEN_GEMM_OS");   // 3: the one-step A images (measurements)
+        if (K % 64 != 0 || (e && e[0] == '3')) return os_launch<false, true, OS_OUT_BF16>(g, stream);
+        static bool asked[16] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+        if (!asked[dev]) {
+            const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_os_kc_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, KC_LDS);
+            if (err != hipSuccess) {
+                mgen_set_error("mgen_gemm_bf16: cannot reserve %d bytes of LDS: %s", KC_LDS, hipGetErrorString(err));
+                return MGEN_ELAUNCH;
+            }
+            asked[dev] = true;
+        }
+        hipLaunchKernelGGL(gemm_os_kc_kernel, dim3(g.nbm * g.nbn), dim3(256), KC_LDS, stream, g);
+        return mgen_check_launch("mgen_gemm_bf16");
+    }
     return out_mode == OS_OUT_RESID_ROUND ? os_launch<false, false, OS_OUT_RESID_ROUND>(g, stream)
                                           : os_launch<false, false, OS_OUT_RESID>(g, stream);
 }

@@ -90,7 +90,11 @@ def test_swiglu_form(ops):
         assert ops.linear_swiglu_fwd(x, w, gu, act)
         return gu, act
 
-    (gu1, act1), (gu0, act0) = _both(run)
+    os.environ["MGEN_GEMM_RS"] = "3"   # the SwiGLU form of the register-panel kernel is opt-in
+    gu1, act1 = run()
+    os.environ["MGEN_GEMM_RS"] = "0"
+    gu0, act0 = run()
+    os.environ.pop("MGEN_GEMM_RS", None)
     assert torch.equal(gu1, gu0) and torch.equal(act1, act0)
     # and against the separate kernels' arithmetic in torch: silu in fp32 from the bf16 gate, rounded, times up
     gf = gu1[:, :I].float()
