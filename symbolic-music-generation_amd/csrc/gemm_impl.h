@@ -728,11 +728,9 @@ extern "C" int mgen_gemm_bf16_swiglu(const void* x, const void* w, void* gu, voi
                      ldgu >= 2 * I && ldact >= I, "mgen_gemm_bf16_swiglu: bad leading dimensions");
     MGEN_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)gu % 16) == 0 &&
                      ((uintptr_t)act % 16) == 0, "mgen_gemm_bf16_swiglu: operands must be 16-byte aligned");
-    // The register-panel kernel has a SwiGLU form too (MGEN_GEMM_RS=3 selects it). Inside the training step it
-    // measured 1.2-2.4 ms per step SLOWER than the tile loop below (its 64-byte gate / up row segments are half cache
-    // lines), although it wins when timed alone: not the default.
+    // the SwiGLU form of the register-panel kernel (MGEN_GEMM_RS=2: its plain form only)
     const char* rs_env = getenv("MGEN_GEMM_RS");
-    if (I % 32 == 0 && rs_env && rs_env[0] == '3' && mgen_gemm_rs_fits(M, 2 * I, K, ldx, ldw, ldgu))
+    if (I % 32 == 0 && !(rs_env && rs_env[0] == '2') && mgen_gemm_rs_fits(M, 2 * I, K, ldx, ldw, ldgu))
         return mgen_gemm_rs_launch(x, w, gu, act, M, 2 * I, I, ldx, ldw, ldgu, ldact, stream);
     GemmArgs g;
     g.A2 = g.B2 = nullptr; g.lda2 = g.ldb2 = 0; g.K1 = 0x7fffffff;

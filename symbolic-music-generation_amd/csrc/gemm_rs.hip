@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     // store the same 128-byte column segment of their rows at the same time (one memory channel for the whole chip
     // whenever the row pitch is a multiple of the channel interleave)
     const int npp = p1 - p0;
-    const int rot = (rp & 15) % npp;
+    // (rotation over 4 KiB worth of column segments when the row pitch is a multiple of 4 KiB - the SwiGLU form's
+    // 64-byte segments at 4 / 8 KiB pitch measured 1.3 ms per training step slower with a 1 KiB span)
+    const int rspan = SW ? 64 : (((g.ldc * 2) & 4095) == 0 ? 32 : 16);
+    const int rot = (rp & (rspan - 1)) % npp;
     auto pair_of = [&](int jp) { int q = jp + rot; if (q >= npp) q -= npp; return p0 + q; };
     auto issue_block = [&](int jl) {
         const int jc = min(jl, nblk - 1);

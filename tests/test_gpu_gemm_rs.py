@@ -90,7 +90,7 @@ def test_swiglu_form(ops):
         assert ops.linear_swiglu_fwd(x, w, gu, act)
         return gu, act
 
-    os.environ["MGEN_GEMM_RS"] = "3"   # the SwiGLU form of the register-panel kernel is opt-in
+    os.environ["MGEN_GEMM_RS"] = "1"
     gu1, act1 = run()
     os.environ["MGEN_GEMM_RS"] = "0"
     gu0, act0 = run()
