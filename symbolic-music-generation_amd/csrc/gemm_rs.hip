@@ -25,10 +25,21 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) float rs_f32x4;
+__device__ __forceinline__ rs_f32x4 mfma16(bf16x8 a, bf16x8 b, rs_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 constexpr int RS_K = 512, RS_KS = RS_K / 16;
 constexpr int RS_ROWS = 256;                       // token rows per workgroup
 constexpr int RS_SLOT = 32 * RS_K * 2;             // one block of 32 rows: 32 KiB
 constexpr int RS_NSLOT = 4;
+#ifndef MGEN_RS_M32
+#define MGEN_RS_M32 0
+#endif
+// The MFMA shape: v_mfma_f32_16x16x32_bf16 (default) or v_mfma_f32_32x32x16_bf16 (-DMGEN_RS_M32=1). Same flops per
+// cycle, same LDS traffic, same registers; the chip holds a higher clock on the 16x16x32 shape under this load.
+constexpr bool RS_M16 = !MGEN_RS_M32;
 constexpr int RS_AHEAD = 3;                        // LDS fragment reads in flight ahead of their MFMAs
 constexpr int RS_STAGE = 8192;                     // per-wave output image: 64 rows x 128 bytes
 constexpr int RS_LDS = RS_NSLOT * RS_SLOT + 4 * RS_STAGE;   // 160 KiB
@@ -114,6 +125,17 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     int raddr[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) raddr[e] = r * 1024 + ((32 * e + 16 * h) ^ (16 * (r & 15)));
+    // 16x16x32 shape: a fragment = 16 rows x 32 reduction indices, lane (i = lane & 15, kq = lane >> 4) takes row i,
+    // indices 32 ks + 8 kq .. + 7 = chunk 4 ks + kq; sub-step u (0..31) of a 32-row block = (ks = u >> 1, rows
+    // 16 (u & 1) ..). The sixteen lanes a ds_read_b128 serves together still hit sixteen different bank groups.
+    const int li = lane & 15, kq = lane >> 4;
+    int raddr16[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) raddr16[e] = li * 1024 + 16 * ((4 * e + kq) ^ li);
+    // byte offset inside a 32-row image of the fragment of sub-step u
+    auto frag_off = [&](int u) {
+        return RS_M16 ? (u & 1) * 16384 + raddr16[(u >> 1) & 3] + 256 * (u >> 3) : raddr[u & 7] + 256 * (u >> 3);
+    };
 
     // ---- the weight stream: blocks of one run in rotated order, so that workgroups that work in step do not all
     // store the same 128-byte column segment of their rows at the same time (one memory channel for the whole chip
@@ -140,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     // ---- the token panel: 2 x 128 rows through the ring (whole 1 KiB rows, like the weight blocks) into registers:
     // fragment (mt, ks) of a lane = row 32 mt + r, reduction indices 16 ks + 8 h .. + 7
     const int mrow0 = rp * RS_ROWS + wave * 64;
-    bf16x8 Af[2][RS_KS];
+    bf16x8 Af[64];   // 32x32x16: [mt (2)][ks (32)]; 16x16x32: [mt (4)][ks (16)]
     {
         const int lda2 = (int)(g.lda * 2);
         const u32x4 rsA = dma_rsrc(g.A, (unsigned)(((long)(g.M - 1) * g.lda + RS_K) * 2));
@@ -158,9 +180,11 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const char* sb = smem + (2 * (wave & 1) + mt) * RS_SLOT;
+                    // 32x32x16: fragment (mt, ks) = sub-step ks; 16x16x32: fragment (2 mt + half, ks) = sub-step 2 ks + half
 #pragma unroll
-                    for (int ks = 0; ks < RS_KS; ++ks)
-                        Af[mt][ks] = *reinterpret_cast<const bf16x8*>(sb + raddr[ks & 7] + 256 * (ks >> 3));
+                    for (int u = 0; u < 32; ++u)
+                        Af[RS_M16 ? (2 * mt + (u & 1)) * 16 + (u >> 1) : mt * 32 + u] =
+                            *reinterpret_cast<const bf16x8*>(sb + frag_off(u));
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -175,11 +199,23 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     // and parked in the wave's LDS image behind the first 8 k-steps of the next block (which accumulates into the
     // other two tiles); once both halves of a pair are parked (8 k-steps into the next pair) the image is read back
     // as whole 128-byte row segments and stored, one slice per two k-steps.
-    f32x16 acc[2][2];
+    f32x16 acc[2][2];          // 32x32x16: [token tile (2)][block of the pair]
+    rs_f32x4 acc16[4][2][2];   // 16x16x32: [token tile (4)][column tile (2)][block of the pair]
     char* st = smem + RS_NSLOT * RS_SLOT + wave * RS_STAGE;
 
     // slice t (0..7) of parking the tiles acc[.][j]: tile row block i = t >> 2, column group g4 -> 8 bytes per lane
     auto park = [&](int j, int t) {
+        if (RS_M16) {
+            // tile (mt = t >> 1, nt = t & 1): lane holds token row 16 mt + li, columns 16 nt + 4 kq .. + 3 of block j
+            const int mt = t >> 1, nt = t & 1;
+            const int row = 16 * mt + li;
+            const int ch = 4 * j + 2 * nt + (kq >> 1);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc16[mt][nt][j][e]);
+            *reinterpret_cast<bf16x4*>(st + row * 128 + ((ch ^ (row & 7)) << 4) + 8 * (kq & 1)) = o;
+            return;
+        }
         const int i = t >> 2, g4 = t & 3;
         const int row = 32 * i + r;
         const int ch = 4 * j + g4;
@@ -226,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
     // front of the barrier that opens block jl, so behind that barrier block jl + 1 is complete for every wave.
     bf16x8 fpre[RS_AHEAD];
 #pragma unroll
-    for (int ks = 0; ks < RS_AHEAD; ++ks) fpre[ks] = *reinterpret_cast<const bf16x8*>(smem + raddr[ks & 7] + 256 * (ks >> 3));
+    for (int ks = 0; ks < RS_AHEAD; ++ks) fpre[ks] = *reinterpret_cast<const bf16x8*>(smem + frag_off(ks));
 
     // one pair of blocks; FIRST: there is no earlier block whose tiles wait to be parked and stored
     // WV = this wave's index as a constant: the four waves run four copies of the loop that differ only in WHEN
@@ -261,20 +297,25 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
             for (int ks = 0; ks < RS_KS; ++ks) {
                 // the fragment of k-step ks + RS_AHEAD is requested in front of the two MFMAs of step ks
                 if (ks + RS_AHEAD < RS_KS)
-                    fb[ks + RS_AHEAD] = *reinterpret_cast<const bf16x8*>(sb + raddr[(ks + RS_AHEAD) & 7] +
-                                                                         256 * ((ks + RS_AHEAD) >> 3));
+                    fb[ks + RS_AHEAD] = *reinterpret_cast<const bf16x8*>(sb + frag_off(ks + RS_AHEAD));
                 else
-                    fpre[ks + RS_AHEAD - RS_KS] = *reinterpret_cast<const bf16x8*>(
-                        sbn + raddr[(ks + RS_AHEAD - RS_KS) & 7] + 256 * ((ks + RS_AHEAD - RS_KS) >> 3));
+                    fpre[ks + RS_AHEAD - RS_KS] = *reinterpret_cast<const bf16x8*>(sbn + frag_off(ks + RS_AHEAD - RS_KS));
                 if (DBG & 8) {
                     asm volatile("" ::"v"(fb[ks]));
+                } else if (RS_M16) {
+                    // sub-step ks = (k-step ks >> 1, column tile ks & 1): one weight fragment, the four token tiles
+                    const int k16 = ks >> 1, nt = ks & 1;
+                    const rs_f32x4 z = {};
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc16[mt][nt][nb] = mfma16(fb[ks], Af[mt * 16 + k16], k16 == 0 ? z : acc16[mt][nt][nb]);
                 } else if (ks == 0) {
                     const f32x16 z = {};
-                    acc[0][nb] = mfma32(fb[ks], Af[0][ks], z);
-                    acc[1][nb] = mfma32(fb[ks], Af[1][ks], z);
+                    acc[0][nb] = mfma32(fb[ks], Af[ks], z);
+                    acc[1][nb] = mfma32(fb[ks], Af[32 + ks], z);
                 } else {
-                    acc[0][nb] = mfma32(fb[ks], Af[0][ks], acc[0][nb]);
-                    acc[1][nb] = mfma32(fb[ks], Af[1][ks], acc[1][nb]);
+                    acc[0][nb] = mfma32(fb[ks], Af[ks], acc[0][nb]);
+                    acc[1][nb] = mfma32(fb[ks], Af[32 + ks], acc[1][nb]);
                 }
                 // piece q of block jl + 3 behind k-step 4 q + WV (the last one, 28 + WV, behind the block's last store)
                 if (!(DBG & 4) && (ks & 3) == WV) {
