@@ -258,6 +258,16 @@ int mgen_notes_to_events(const float* rows, long n, float ticks_per_second, int*
 
 /* dtype conversion: kind 0 fp32 -> bf16, 1 bf16 -> fp32. */
 int mgen_cast(const void* in, void* out, long n, int kind, mgen_stream_t stream);
+/* Weight gradients of up to four linear layers that share the token range, as ONE launch: C_i [M_i][N_i] (fp32, added in
+ * place) += A_i^T B_i with A_i = dY_i stored [K][M_i], B_i = X_i stored [K][N_i] (host arrays of n pointers / sizes).
+ * Replaces n grad_weight products of autograd's mm backward (grad_output^T @ input of nn.Linear, reached from
+ * models/qwen3/modeling_qwen3.py:76-83,225-236); numbering the tiles of all products through means a quarter of the
+ * reduction slices (and fp32 atomics) that n separate calls need. Each product must satisfy what the
+ * output-stationary kernel needs (K a multiple of 32 and >= 2048, M_i, N_i >= 256 and multiples of 8). */
+int mgen_gemm_bf16_wgrad_group(int n, const void* const* A, const void* const* B, float* const* C, const int* M,
+                               const int* N, int K, const long* lda, const long* ldb, const long* ldc,
+                               mgen_stream_t stream);
+
 /* out[b] [C][R] = in[b] [R][C]^T for nbatch bf16 matrices bs_in / bs_out elements apart. Replaces the transposed
  * operand read inside autograd's mm backward (grad_input = grad_output @ weight, torch/csrc/autograd FunctionsManual
  * mm_mat1_backward as reached from nn.Linear in models/qwen3/modeling_qwen3.py:76-83): the host keeps transposed bf16

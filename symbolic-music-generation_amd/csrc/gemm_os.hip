@@ -45,14 +45,10 @@ struct OsArgs {
 };
 
 // AKM / BKM: the operand is stored [reduction][output index] (else [output index][reduction])
+// t = tile of the product g, kslice = reduction slice (the caller maps workgroups to them)
 template <bool AKM, bool BKM, int OUT, int WV>
-__device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, int wave) {
+__device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, int wave, int t, int kslice) {
     constexpr bool ROWMAJOR_OUT = OUT != OS_OUT_F32 && OUT != OS_OUT_F32_ACC;
-    const int nt = g.nbm * g.nbn;
-    const int wid = xcd_remap(blockIdx.x, nt * g.splitk);
-    // slice-major: the tiles of one reduction slice are neighbours and share that slice of both operands in L2;
-    // tiles of one tile row (same A rows) are neighbours too
-    const int kslice = wid / nt, t = wid % nt;
     const int tm = t / g.nbn, tn = t % g.nbn;
     const int m0 = tm * 256, n0 = tn * 256;
     const int kbeg = kslice * g.kper;
@@ -432,12 +428,49 @@ __global__ __launch_bounds__(256, 1) void gemm_os_kernel(OsArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // slice-major: the tiles of one reduction slice are neighbours and share that slice of both operands in L2;
+    // tiles of one tile row (same A rows) are neighbours too
+    const int nt = g.nbm * g.nbn;
+    const int wid = xcd_remap(blockIdx.x, nt * g.splitk);
+    const int kslice = wid / nt, t = wid % nt;
     // four copies of the loop that differ only in where the wave's DMA pieces sit between its MFMAs
     switch (wave) {
-        case 0: os_body<AKM, BKM, OUT, 0>(g, smem, lane, wave); break;
-        case 1: os_body<AKM, BKM, OUT, 1>(g, smem, lane, wave); break;
-        case 2: os_body<AKM, BKM, OUT, 2>(g, smem, lane, wave); break;
-        default: os_body<AKM, BKM, OUT, 3>(g, smem, lane, wave); break;
+        case 0: os_body<AKM, BKM, OUT, 0>(g, smem, lane, wave, t, kslice); break;
+        case 1: os_body<AKM, BKM, OUT, 1>(g, smem, lane, wave, t, kslice); break;
+        case 2: os_body<AKM, BKM, OUT, 2>(g, smem, lane, wave, t, kslice); break;
+        default: os_body<AKM, BKM, OUT, 3>(g, smem, lane, wave, t, kslice); break;
+    }
+}
+
+// Several weight gradients over the same reduction range (the four of a decoder layer) as ONE launch: their tiles are
+// numbered through, so the reduction range is cut into as few slices as fill the chip once - a quarter of the slices,
+// and of the fp32 atomics, that four separate launches need.
+constexpr int OS_GROUP_MAX = 4;
+struct OsGroupArgs {
+    OsArgs p[OS_GROUP_MAX];
+    int first_tile[OS_GROUP_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256, 1) void gemm_os_group_kernel(OsGroupArgs gg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nt = gg.first_tile[gg.n];
+    const int wid = xcd_remap(blockIdx.x, nt * gg.p[0].splitk);
+    const int kslice = wid / nt;
+    int t = wid % nt;
+    int which = 0;
+#pragma unroll
+    for (int q = 1; q < OS_GROUP_MAX; ++q)
+        if (q < gg.n && t >= gg.first_tile[q]) which = q;
+    t -= gg.first_tile[which];
+    const OsArgs& g = gg.p[which];
+    switch (wave) {
+        case 0: os_body<true, true, OS_OUT_F32_ACC, 0>(g, smem, lane, wave, t, kslice); break;
+        case 1: os_body<true, true, OS_OUT_F32_ACC, 1>(g, smem, lane, wave, t, kslice); break;
+        case 2: os_body<true, true, OS_OUT_F32_ACC, 2>(g, smem, lane, wave, t, kslice); break;
+        default: os_body<true, true, OS_OUT_F32_ACC, 3>(g, smem, lane, wave, t, kslice); break;
     }
 }
 
@@ -531,4 +564,53 @@ int mgen_gemm_os_launch(const void* A, const void* B, void* C, const void* resid
     }
     return out_mode == OS_OUT_RESID_ROUND ? os_launch<false, false, OS_OUT_RESID_ROUND>(g, stream)
                                           : os_launch<false, false, OS_OUT_RESID>(g, stream);
+}
+
+// dW_i (fp32, added in place) += dY_i^T X_i for n <= 4 products over the same K tokens, one launch
+extern "C" int mgen_gemm_bf16_wgrad_group(int n, const void* const* A, const void* const* B, float* const* C,
+                                          const int* M, const int* N, int K, const long* lda, const long* ldb,
+                                          const long* ldc, hipStream_t stream) {
+    MGEN_REQUIRE(n >= 1 && n <= OS_GROUP_MAX && A && B && C && M && N && lda && ldb && ldc,
+                 "mgen_gemm_bf16_wgrad_group: bad arguments");
+    OsGroupArgs gg;
+    gg.n = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        MGEN_REQUIRE(A[i] && B[i] && C[i], "mgen_gemm_bf16_wgrad_group: null operand");
+        MGEN_REQUIRE(((uintptr_t)A[i] % 16) == 0 && ((uintptr_t)B[i] % 16) == 0,
+                     "mgen_gemm_bf16_wgrad_group: operands must be 16-byte aligned");
+        MGEN_REQUIRE(mgen_gemm_os_fits(M[i], N[i], K, lda[i], ldb[i], ldc[i], 0, 1, 1, OS_OUT_F32_ACC) &&
+                         lda[i] >= M[i] && ldb[i] >= N[i] && ldc[i] >= N[i],
+                     "mgen_gemm_bf16_wgrad_group: product %d (M=%d N=%d K=%d) does not fit the output-stationary kernel",
+                     i, M[i], N[i], K);
+        OsArgs& g = gg.p[i];
+        g.A = (const bf16*)A[i]; g.B = (const bf16*)B[i]; g.C = C[i]; g.R = nullptr;
+        g.lda = lda[i]; g.ldb = ldb[i]; g.ldc = ldc[i]; g.ldr = 0; g.M = M[i]; g.N = N[i]; g.K = K;
+        g.nbm = (M[i] + 255) / 256; g.nbn = (N[i] + 255) / 256;
+        gg.first_tile[i] = tiles;
+        tiles += g.nbm * g.nbn;
+    }
+    for (int i = n; i <= OS_GROUP_MAX; ++i) gg.first_tile[i] = tiles;
+    const int steps = K / OS_BK;
+    int sk = tiles < 256 ? 256 / tiles : 1;
+    const int maxsk = steps / 32;
+    if (sk > maxsk) sk = maxsk;
+    if (sk < 1) sk = 1;
+    const int per = (steps + sk - 1) / sk;
+    const int splitk = (steps + per - 1) / per;
+    for (int i = 0; i < n; ++i) { gg.p[i].kper = per * OS_BK; gg.p[i].splitk = splitk; }
+    static bool asked[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!asked[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_os_group_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, OS_LDS);
+        if (e != hipSuccess) {
+            mgen_set_error("mgen_gemm_bf16_wgrad_group: cannot reserve %d bytes of LDS: %s", OS_LDS, hipGetErrorString(e));
+            return MGEN_ELAUNCH;
+        }
+        asked[dev] = true;
+    }
+    hipLaunchKernelGGL(gemm_os_group_kernel, dim3(tiles * splitk), dim3(256), OS_LDS, stream, gg);
+    return mgen_check_launch("mgen_gemm_bf16_wgrad_group");
 }

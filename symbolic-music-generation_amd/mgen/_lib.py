@@ -68,6 +68,7 @@ SIGNATURES = {
     "mgen_notes_to_events": [P, L, F, P, P, P],
     "mgen_cast": [P, P, L, I, P],
     "mgen_transpose_bf16": [P, P, I, I, L, L, I, L, L, P],
+    "mgen_gemm_bf16_wgrad_group": [I, P, P, P, P, P, I, P, P, P, P],
     "mgen_ce_count": [P, L, I, L, P, P, L, P, P],
     "mgen_check_right_padding": [P, I, I, P, P],
     "mgen_ce_fwd_bwd": [P, P, L, L, I, L, I, L, P, F, P, P, I, I, P],

@@ -661,6 +661,11 @@ class MidiLM(GenerationMixin, nn.Module):
         lo = self.lora
         dh = torch.empty(T, d, dtype=torch.float32, device=dev)
         dh_lp = torch.empty(T, d, dtype=bf, device=dev)
+        # Without adapters the four weight gradients of a layer run as ONE launch at the end of the layer (a quarter of
+        # the reduction slices and atomics of four launches): the low-precision residual gradient the MLP branch saw
+        # must then outlive the one the attention branch sees, hence a second buffer.
+        group = lo is None and not f32
+        dh_lp_att = torch.empty(T, d, dtype=bf, device=dev) if group else dh_lp
         g_norm = self._view(self.flat_grad, "model.norm.weight")
         ops.rmsnorm_bwd(dxN, h_last, self.model.norm.weight, rstdN, dh, dh_lp, g_norm, accumulate=False)
         if grad_hook is not None:
@@ -684,9 +689,9 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.linear_dgrad_t(dh_lp, wt[1][l], dact)
             else:
                 ops.linear_dgrad(dh_lp, v.s_down, dact)
-            if la is None:
+            if la is None and not group:
                 ops.linear_wgrad(dh_lp, act, v.g_down)
-            elif not fused:
+            elif la is not None and not fused:
                 lo.bwd(dh_lp, act, lts[3], la["down"].sA, la["down"].sB, la["down"].gA, la["down"].gB, dact, I, d,
                        key=lts[4][4])
             ops.swiglu_bwd(gu, dact, dgu)
@@ -694,14 +699,16 @@ class MidiLM(GenerationMixin, nn.Module):
                 lo.bwd_fused_gu(dgu, x2, lts[2], v.s_gu, la, dx, d, I)
             else:
                 ops.linear_dgrad(dgu, v.s_gu, dx)
-            if la is None:
+            if la is None and not group:
                 ops.linear_wgrad(dgu, x2, v.g_gu)
-            elif not fused:
+            elif la is not None and not fused:
                 r_ = lo.r
                 lo.bwd(dgu[:, :I], x2, lts[2][:, :r_], la["gate"].sA, la["gate"].sB, la["gate"].gA, la["gate"].gB,
                        dx, d, I, key=lts[4][2])
                 lo.bwd(dgu[:, I:], x2, lts[2][:, r_:2 * r_], la["up"].sA, la["up"].sB, la["up"].gA, la["up"].gB, dx, d, I,
                        key=lts[4][3])
+            dh_mlp = dh_lp            # what the MLP branch's weight gradients were taken from
+            dh_lp = dh_lp_att         # (the same buffer unless the weight gradients are grouped)
             ops.rmsnorm_bwd(dx, h_mid, v.w_ln2, rstd2, dh, dh_lp, v.g_ln2, accumulate=True)
             # ---- attention branch
             if fused:
@@ -710,9 +717,9 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.linear_dgrad_t(dh_lp, wt[0][l], datt)
             else:
                 ops.linear_dgrad(dh_lp, v.s_o, datt)
-            if la is None:
+            if la is None and not group:
                 ops.linear_wgrad(dh_lp, att_o, v.g_o)
-            elif not fused:
+            elif la is not None and not fused:
                 lo.bwd(dh_lp, att_o, lts[1], la["o"].sA, la["o"].sB, la["o"].gA, la["o"].gB, datt, H * Dh, d,
                        key=lts[4][1])
             dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + esz * H * Dh, dqkv.data_ptr() + esz * QK
@@ -736,11 +743,15 @@ class MidiLM(GenerationMixin, nn.Module):
                 lo.bwd_fused(dqkv, x1, lts[0], v.s_qkv, la, "qkv", dx, d, NQ)
             else:
                 ops.linear_dgrad(dqkv, v.s_qkv, dx)
-            if la is None:
+            if la is None and not group:
                 ops.linear_wgrad(dqkv, x1, v.g_qkv)
-            elif not fused:
+            elif la is not None and not fused:
                 lo.bwd(dqkv, x1, lts[0], la["qkv"].sA, la["qkv"].sB, la["qkv"].gA, la["qkv"].gB, dx, d, NQ,
                        key=lts[4][0])
+            if group:
+                ops.linear_wgrad_group([(dh_mlp, act, v.g_down), (dgu, x2, v.g_gu), (dh_lp, att_o, v.g_o),
+                                        (dqkv, x1, v.g_qkv)])
+            dh_lp = dh_mlp            # the next layer's MLP branch reads (and keeps) this one
             ops.rmsnorm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, accumulate=True)
             saved[l] = None
             if grad_hook is not None:

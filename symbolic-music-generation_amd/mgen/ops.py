@@ -1,6 +1,8 @@
 """Tensor-level wrappers over the C-ABI kernels: take torch CUDA(HIP) tensors, pass raw device pointers, sizes,
 strides and the current HIP stream. torch is used for device memory and streams only; every computation below runs
 in libmgen_hip.so."""
+import os
+
 import torch
 
 from ._lib import call
@@ -135,6 +137,32 @@ def linear_wgrad(dy, x, dw, accumulate=True, n_rows=None, n_cols=None):
     K = n_cols if n_cols is not None else x.shape[1]
     gemm_any(dy, x, dw, N, K, T, dy.stride(0), x.stride(0), dw.stride(0), True, True,
              OUT_F32_ACC if accumulate else OUT_F32)
+
+
+def linear_wgrad_group(items):
+    """items = [(dy [T, N_i], x [T, K_i], dw [N_i, K_i] fp32), ...] (at most 4, same T): dw_i += dy_i^T @ x_i in one
+    launch when every product fits the output-stationary kernel, else one by one."""
+    import ctypes
+    n = len(items)
+    T = items[0][0].shape[0]
+    ok = 1 <= n <= 4 and os.environ.get("MGEN_WGRAD_GROUP", "1") != "0" and T % 32 == 0 and T >= 2048
+    for dy, x, dw in items:
+        ok = ok and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and \
+            dy.shape[0] == T and x.shape[0] == T and dy.shape[1] >= 256 and x.shape[1] >= 256 and \
+            dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and \
+            T * dy.stride(0) * 2 < (1 << 32) and T * x.stride(0) * 2 < (1 << 32)
+    if not ok:
+        for dy, x, dw in items:
+            linear_wgrad(dy, x, dw)
+        return
+    _need_gpu(*[t for it in items for t in it])
+    vp = ctypes.c_void_p * n
+    ci = ctypes.c_int * n
+    cl = ctypes.c_long * n
+    call("mgen_gemm_bf16_wgrad_group", n, vp(*[_p(i[0]) for i in items]), vp(*[_p(i[1]) for i in items]),
+         vp(*[_p(i[2]) for i in items]), ci(*[i[0].shape[1] for i in items]), ci(*[i[1].shape[1] for i in items]), T,
+         cl(*[i[0].stride(0) for i in items]), cl(*[i[1].stride(0) for i in items]),
+         cl(*[i[2].stride(0) for i in items]), _stream())
 
 
 def gemm_bias(a, b, c, bias, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode=OUT_BF16, resid=None,

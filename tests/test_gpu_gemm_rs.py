@@ -201,3 +201,30 @@ def test_output_stationary_row_major_outputs(ops, kind):
     ref = prod if res is None else prod.to(torch.bfloat16).float() + res[rows]
     err = float((outs[0][rows].float() - ref).abs().max() / ref.abs().max())
     assert err < 1e-2, err
+
+
+def test_grouped_weight_gradients(ops):
+    """mgen_gemm_bf16_wgrad_group: four products over the same tokens in one launch against the four separate calls
+    (the grouping changes only how the reduction range is cut, i.e. the summation order)."""
+    T = 8192
+    g = torch.Generator().manual_seed(31)
+    shapes = [(512, 2048), (4096, 512), (512, 1024), (3072, 512)]   # (N_i, K_i) of down, gate/up, o, qkv
+    items, refs = [], []
+    for n, k in shapes:
+        dy = (torch.randn(T, n, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+        x = (torch.randn(T, k, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+        dw = torch.full((n, k), 2.0, dtype=torch.float32, device=dev())
+        items.append((dy, x, dw))
+        refs.append(dy.float().t() @ x.float() + 2.0)
+    ops.linear_wgrad_group(items)
+    for (dy, x, dw), ref in zip(items, refs):
+        sep = torch.full_like(dw, 2.0)
+        ops.linear_wgrad(dy, x, sep)
+        scale = float(ref.abs().max())
+        assert float((dw - ref).abs().max()) / scale < 2e-5
+        assert float((dw - sep).abs().max()) / scale < 2e-6
+    # products that do not fit the kernel fall back to separate calls
+    small = [(items[0][0][:96], items[0][1][:96], torch.zeros_like(items[0][2]))]
+    ops.linear_wgrad_group(small)
+    ref = small[0][0].float().t() @ small[0][1].float()
+    assert float((small[0][2] - ref).abs().max()) / float(ref.abs().max()) < 2e-5
