@@ -145,7 +145,8 @@ def linear_wgrad_group(items):
     import ctypes
     n = len(items)
     T = items[0][0].shape[0]
-    ok = 1 <= n <= 4 and os.environ.get("MGEN_WGRAD_GROUP", "1") != "0" and T % 32 == 0 and T >= 2048
+    ok = 1 <= n <= 4 and os.environ.get("MGEN_WGRAD_GROUP", "1") != "0" and \
+        os.environ.get("MGEN_GEMM_OS", "1") != "0" and T % 32 == 0 and T >= 2048
     for dy, x, dw in items:
         ok = ok and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dw.dtype == torch.float32 and \
             dy.shape[0] == T and x.shape[0] == T and dy.shape[1] >= 256 and x.shape[1] >= 256 and \
