@@ -508,8 +508,11 @@ bool mgen_gemm_os_fits(int M, int N, int K, long lda, long ldb, long ldc, long l
     if (!(wgrad || (dgrad && !(e && e[0] == '4')) || (proj && e && e[0] == '2'))) return false;
     if (wgrad) {
         if (K < 2048 || (M % 8) || (N % 8)) return false;
-        // buffer offsets are 32-bit: one workgroup's reduction slice of either operand
-        if ((long)K * lda * 2 >= (1L << 32) || (long)K * ldb * 2 >= (1L << 32)) return false;
+        // buffer offsets are 32-bit: one workgroup's reduction slice of either operand must stay below 4 GiB. A product
+        // that is added to its output can be cut into slices for that (slices of at least 1024 rows), a plain store not
+        const long ldmax = lda > ldb ? lda : ldb;
+        const long rows = out_mode == OS_OUT_F32_ACC ? (K < 1024 ? K : 1024) : K;
+        if (rows * ldmax * 2 >= (1L << 32)) return false;
         return true;
     }
     // the products with few output columns: whole 256-row tiles (rows beyond the operand would be read), at least as
@@ -537,6 +540,13 @@ int mgen_gemm_os_launch(const void* A, const void* B, void* C, const void* resid
         const int maxsk = steps / 32;
         if (sk > maxsk) sk = maxsk;
         if (sk < 1) sk = 1;
+    }
+    if (out_mode == OS_OUT_F32_ACC) {
+        // and at least as many slices as keep a slice of either operand below 4 GiB (32-bit buffer offsets)
+        const long ldmax = lda > ldb ? lda : ldb;
+        const long max_rows = ((1L << 32) - 1) / (ldmax * 2) / OS_BK * OS_BK;
+        const int need = (int)((K + max_rows - 1) / max_rows);
+        if (sk < need) sk = need;
     }
     const int per = (steps + sk - 1) / sk;
     g.kper = per * OS_BK;

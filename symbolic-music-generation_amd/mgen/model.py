@@ -16,6 +16,7 @@ dgrad/wgrad GEMMs and the fused norm/rope/attention backward kernels.
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -28,6 +29,10 @@ from .generation import GenerationMixin
 
 _ALIGN = 64  # every tensor starts at a multiple of 64 elements in the flat buffers
 POS4D_HEAD_OUT = 16  # 4-D position model: 8 (cos, sin) pairs (/root/reference/src/model/modeling.py:560)
+
+
+# MGEN_LM_WGRAD_8K=1: the lm_head weight gradient in launches of 8192 tokens (same-box comparisons)
+_LM_WGRAD_8K = os.environ.get("MGEN_LM_WGRAD_8K", "0") == "1"
 
 
 class CausalLMOutput:
@@ -623,8 +628,9 @@ class MidiLM(GenerationMixin, nn.Module):
                 # dxN[c] = dlogits[c] @ W ; dW += dlogits[c]^T @ xN[c]
                 dl = ops.presplit(logits)
                 ops.gemm_any(dl, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
-                # the weight-gradient product runs over 8192 tokens per launch: its workgroups stream the whole
-                # reduction range and stay in step (sharing the activation rows in L2) only over a short range
+                # the weight-gradient product: the very first launch stores (8192 tokens), everything after it is
+                # added, as much of the chunk per launch as possible (the kernel cuts the token range into slices
+                # of less than 4 GiB of dlogits rows; one launch wastes less in its last round of workgroups)
                 if self.lora is not None:
                     pass   # frozen base: no weight gradient for the head
                 elif isinstance(dl, ops.W2):
@@ -632,11 +638,13 @@ class MidiLM(GenerationMixin, nn.Module):
                                  ops.OUT_F32 if first else ops.OUT_F32_ACC)
                     first = False
                 else:
-                    for r0 in range(0, n, 8192):
-                        rn = min(8192, n - r0)
+                    r0 = 0
+                    while r0 < n:
+                        rn = min(8192, n - r0) if (first or _LM_WGRAD_8K) else n - r0
                         ops.gemm(dl[r0:r0 + rn], xc[r0:r0 + rn], grad_buf, V, d, rn, ld, xc.stride(0), d,
                                  True, True, ops.OUT_F32 if first else ops.OUT_F32_ACC)
                         first = False
+                        r0 += rn
         loss = torch.empty((), dtype=torch.float32, device=dev)
         ops.ce_finalize(row_loss, inv_count, loss)
         return loss, dxN

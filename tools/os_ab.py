@@ -21,7 +21,7 @@ def timeit(fn, n=10):
 ok = True
 for name, M, N, K, acc in [("qkv wgrad", 3072, 512, 65536, True), ("gu wgrad", 4096, 512, 65536, True),
                            ("o wgrad", 512, 1024, 65536, True), ("down wgrad", 512, 2048, 65536, True),
-                           ("lm wgrad 8k", 151936, 512, 8192, True), ("lm wgrad 32k", 151936, 512, 32768, True),
+                           ("lm wgrad 8k", 151936, 512, 8192, True), ("lm wgrad 24k", 151936, 512, 24576, True), ("lm wgrad 32k", 151936, 512, 32768, True),
                            ("lm wgrad store", 151936, 512, 8192, False), ("ragged", 1000, 520, 4096, True)]:
     a = (torch.randn(K, M, device=dev) * 0.5).to(torch.bfloat16)
     b = (torch.randn(K, N, device=dev) * 0.5).to(torch.bfloat16)
@@ -35,7 +35,7 @@ for name, M, N, K, acc in [("qkv wgrad", 3072, 512, 65536, True), ("gu wgrad", 4
         ts.append(timeit(run))
     err = float((outs[0] - outs[1]).abs().max() / outs[0].abs().max())
     fl = 2.0 * M * N * K
-    good = err < 2e-6
+    good = err < 1e-5
     ok &= good
     print(f"{name:16s} M={M:6d} N={N:5d} K={K:6d}: old {ts[0]:8.1f} us ({fl/ts[0]/1e6:7.1f} TF/s)  new {ts[1]:8.1f} us "
           f"({fl/ts[1]/1e6:7.1f} TF/s)  rel diff {err:.1e} {'ok' if good else 'BAD'}", flush=True)
