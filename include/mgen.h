@@ -165,6 +165,11 @@ int mgen_dropout_resid(const void* y, const float* resid, float* out, long n, fl
  * TF models/qwen3/modeling_qwen3.py:81-83. round_silu=1 rounds silu(gate) to bf16 first (autocast behaviour). */
 int mgen_swiglu_fwd(const void* gu, void* act, long T, int I, int round_silu, mgen_stream_t stream);
 int mgen_swiglu_bwd(const void* gu, const void* dact, void* dgu, long T, int I, mgen_stream_t stream);
+/* The same with row pitches in elements (activation rows padded so that their pitch is not a multiple of the memory
+ * channel period: a kernel whose workgroups read the same column segment of many rows in step otherwise queues on one
+ * channel). */
+int mgen_swiglu_bwd_ld(const void* gu, long ldgu, const void* dact, long lddact, void* dgu, long lddgu, long T, int I,
+                       mgen_stream_t stream);
 /* The gate/up projection and the gate in one launch: gu[M][2I] = x[M][K] * w[2I][K]^T (w = gate rows, then up rows) and
  * act[M][I] = silu(gate) * up from the product's epilogue, same rounding as mgen_swiglu_fwd(round_silu = 1) on the stored
  * gu — gate_proj, up_proj and act_fn of Qwen3MLP.forward, TF models/qwen3/modeling_qwen3.py:81-83. K % 64 == 0,

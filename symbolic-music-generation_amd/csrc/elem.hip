@@ -35,15 +35,16 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16* __restrict_
 
 // dgu [T, 2I] = [dgate | dup] from dact [T, I] and the saved gu
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dact,
-                                                         bf16* __restrict__ dgu, long T, int I) {
+                                                         bf16* __restrict__ dgu, long T, int I, long ldgu, long lddact,
+                                                         long lddgu) {
     const long nvec = T * (I / 8);
     const int vpr = I / 8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         const long t = i / vpr;
         const int c = (int)(i % vpr) * 8;
-        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + t * 2 * I + c);
-        const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + t * 2 * I + I + c);
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dact + t * I + c);
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + t * ldgu + c);
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + t * ldgu + I + c);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dact + t * lddact + c);
         bf16x8 dg, du;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict_
             du[e] = (bf16)(df * silu);
             dg[e] = (bf16)(df * uf * (sg * (1.f + gf * (1.f - sg))));
         }
-        *reinterpret_cast<bf16x8*>(dgu + t * 2 * I + c) = dg;
-        *reinterpret_cast<bf16x8*>(dgu + t * 2 * I + I + c) = du;
+        *reinterpret_cast<bf16x8*>(dgu + t * lddgu + c) = dg;
+        *reinterpret_cast<bf16x8*>(dgu + t * lddgu + I + c) = du;
     }
 }
 
@@ -122,8 +123,19 @@ extern "C" int mgen_swiglu_fwd(const void* gu, void* act, long T, int I, int rou
 extern "C" int mgen_swiglu_bwd(const void* gu, const void* dact, void* dgu, long T, int I, hipStream_t stream) {
     MGEN_REQUIRE(gu && dact && dgu && T > 0 && I > 0 && I % 8 == 0, "mgen_swiglu_bwd: bad arguments");
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(T * (I / 8), 256, 8192)), dim3(256), 0, stream,
-                       (const bf16*)gu, (const bf16*)dact, (bf16*)dgu, T, I);
+                       (const bf16*)gu, (const bf16*)dact, (bf16*)dgu, T, I, 2L * I, (long)I, 2L * I);
     return mgen_check_launch("mgen_swiglu_bwd");
+}
+
+// the same with row pitches (elements) of gu [T, 2I], dact [T, I] and dgu [T, 2I]
+extern "C" int mgen_swiglu_bwd_ld(const void* gu, long ldgu, const void* dact, long lddact, void* dgu, long lddgu, long T,
+                                  int I, hipStream_t stream) {
+    MGEN_REQUIRE(gu && dact && dgu && T > 0 && I > 0 && I % 8 == 0, "mgen_swiglu_bwd_ld: bad arguments");
+    MGEN_REQUIRE(ldgu >= 2L * I && lddact >= I && lddgu >= 2L * I && ldgu % 8 == 0 && lddact % 8 == 0 && lddgu % 8 == 0,
+                 "mgen_swiglu_bwd_ld: row pitches must cover the rows and be multiples of 8 elements");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(T * (I / 8), 256, 8192)), dim3(256), 0, stream,
+                       (const bf16*)gu, (const bf16*)dact, (bf16*)dgu, T, I, ldgu, lddact, lddgu);
+    return mgen_check_launch("mgen_swiglu_bwd_ld");
 }
 
 extern "C" int mgen_embedding_fwd(const long* ids, const float* table, float* out, long T, int d, long V, int* err_flag,

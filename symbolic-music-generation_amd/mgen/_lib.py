@@ -38,6 +38,7 @@ SIGNATURES = {
     "mgen_dropout_resid": [P, P, P, L, F, U64, P],
     "mgen_swiglu_fwd": [P, P, L, I, I, P],
     "mgen_swiglu_bwd": [P, P, P, L, I, P],
+    "mgen_swiglu_bwd_ld": [P, L, P, L, P, L, L, I, P],
     "mgen_gemm_bf16_swiglu": [P, P, P, P, I, I, I, L, L, L, L, P],
     "mgen_comm_unique_id": [P],
     "mgen_comm_rccl_version": [P],

@@ -426,6 +426,9 @@ def swiglu_bwd(gu, dact, dgu):
     T, I = dact.shape
     if gu.dtype == torch.float32:
         call("mgen_swiglu_f32_bwd", _p(gu), _p(dact), _p(dgu), T, I, _stream())
+    elif gu.stride(0) != 2 * I or dact.stride(0) != I or dgu.stride(0) != 2 * I:
+        call("mgen_swiglu_bwd_ld", _p(gu), gu.stride(0), _p(dact), dact.stride(0), _p(dgu), dgu.stride(0), T, I,
+             _stream())
     else:
         call("mgen_swiglu_bwd", _p(gu), _p(dact), _p(dgu), T, I, _stream())
 
