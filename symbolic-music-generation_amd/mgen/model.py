@@ -563,10 +563,11 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.qkvnorm_rope4d_fwd(qkv.data_ptr(), NQ, qp, kp, vp, NQ, NQ, NQ, v.w_qn, v.w_kn, cs, T, H, KVH, KVH,
                                        Dh, cfg.rms_norm_eps, is_bf16=not f32)
             else:
-                qk = torch.empty(T, QK, dtype=bf, device=dev)
+                qk = torch.empty(T, QK + (qpad if (QK * esz) % 2048 == 0 else 0), dtype=bf, device=dev)[:, :QK]
+                LK = qk.stride(0)
                 qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qkv.data_ptr() + esz * QK
-                sq, sk, sv = QK, QK, LQ
-                ops.qknorm_rope_fwd(qkv, LQ, qp, kp, QK, QK, v.w_qn, v.w_kn, cs, pos, S, T, H, KVH, Dh,
+                sq, sk, sv = LK, LK, LQ
+                ops.qknorm_rope_fwd(qkv, LQ, qp, kp, LK, LK, v.w_qn, v.w_kn, cs, pos, S, T, H, KVH, Dh,
                                     cfg.rms_norm_eps)
             if cache is not None:  # prefill: rotated keys and values of every prompt position go into the cache
                 ops.kv_append(kp, vp, sk, sv, cache.k[l], cache.v[l], cache.zero_pos, B, S, KVH, Dh, cache.max_len)
@@ -752,7 +753,7 @@ class MidiLM(GenerationMixin, nn.Module):
                 sq = sk = sv = NQ
             else:
                 qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qkv.data_ptr() + esz * QK
-                sq, sk, sv = QK, QK, qkv.stride(0)
+                sq, sk, sv = qk.stride(0), qk.stride(0), qkv.stride(0)
             ops.attn_bwd(qp, kp, vp, att.data_ptr(), datt.data_ptr(), lse, delta, dqp, dkp, dvp,
                          sq, sk, sv, H * Dh, H * Dh, LDQ, LDQ, LDQ, B, S, H, KVH, Dh, scale, f32=f32)
             if cfg.pos4d:
