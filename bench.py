@@ -223,8 +223,11 @@ def main():
         if (B, S) == (32, 2048) and args.model == "default" and os.path.exists(pmc):
             with open(pmc) as fh:
                 traffic = json.load(fh).get("roofline_kernel_avg_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": "gemm_rs_kernel<false, 0> (bf16 products with a 512-long reduction: QKV, lm_head logits, "
-                              "o_proj / down_proj input gradients)",
+        # (the other --model choices have no 512-long reductions: their x @ W^T products run on the tile-loop kernel)
+        kname = ("gemm_rs_kernel<false, 0> (bf16 products with a 512-long reduction: QKV, lm_head logits, "
+                 "o_proj / down_proj input gradients)") if cfg.hidden_size == 512 and args.model == "default" else \
+            "x @ W^T products with a bf16 output (all shapes of this model; kernel chosen per shape)"
+        roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (PMC, profiles/r02_pmc_traffic.json); algorithmic: "
