@@ -116,6 +116,10 @@ int mgen_cos4d_count(const float* labels, long T, float* inv_count, int* count, 
  * dpairs [T][16] (type of pairs, optional) = grad_scale * d(mean loss)/d(pairs). */
 int mgen_cos4d_fwd_bwd(const void* pairs, const float* labels, const float* inv_count, float grad_scale,
                        float* pred_out, float* row_loss, void* dpairs, long T, int is_bf16, mgen_stream_t stream);
+/* The eight per-pair means the reference logs beside the loss ("loss/s_0" ... "loss/v_1", reference
+ * src/model/modeling.py:646-655): out8[j] = mean over the rows that count of 1 - <pred pair j, target pair j>
+ * (pred [T][16] fp32 unit pairs from mgen_cos4d_fwd_bwd); zeros when no row counts. Their mean is the loss. */
+int mgen_cos4d_components(const float* pred, const float* labels, long T, float* out8, mgen_stream_t stream);
 /* process_last_logits + the start-time accumulation of generate_music (reference generate_music.py:110-142,173-174):
  * next[b][0..3] = note decoded from the 8 unit pairs pred[b][0..15], start = decoded delta + prev[b][0]. */
 int mgen_pos4d_next(const float* pred, long ld_pred, const float* prev, long ld_prev, float* next, long ld_next, int B,

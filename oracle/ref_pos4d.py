@@ -161,6 +161,17 @@ def cosine_loss(pred: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return (1 - cos_sim).mean()
 
 
+def component_losses(pred: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """The eight values the reference logs as loss/s_0, s_1, d_0, d_1, p_0, p_1, v_0, v_1
+    (/root/reference/src/model/modeling.py:646-655): column means of 1 - cos_sim over the rows that count; [8]."""
+    target = compute_encoding(labels)
+    mask = (labels != -100).all(dim=-1)
+    if not bool(mask.any()):
+        return torch.zeros(8)
+    cos_sim = (pred[mask] * target[mask]).sum(dim=-1)
+    return (1 - cos_sim).mean(dim=0)
+
+
 def forward_pos4d(p: Dict[str, torch.Tensor], cfg: LMConfig, position_tensors: torch.Tensor,
                   labels: Optional[torch.Tensor] = None, mode: str = "fp32", cache: Optional[KVCache] = None,
                   cpu_autocast_head: bool = False):

@@ -116,6 +116,37 @@ __global__ __launch_bounds__(256) void cos4d_kernel(const IoT* __restrict__ pair
     }
 }
 
+// out8[j] = mean over the rows that count of 1 - cos_sim of pair j (pred holds unit pairs), 0 when no row counts.
+// One workgroup; thread sums in double in a fixed order, so the eight values are reproducible.
+__global__ __launch_bounds__(1024) void cos4d_components_kernel(const float* __restrict__ pred,
+                                                                  const float* __restrict__ labels, long T,
+                                                                  float* __restrict__ out8) {
+    __shared__ double red[1024];
+    __shared__ int cnt[128];
+    const int j = threadIdx.x & 7;
+    const int lane_row = threadIdx.x >> 3;   // 128 rows per sweep
+    double acc = 0.0;
+    int c = 0;
+    for (long t = lane_row; t < T; t += 128) {
+        const float* lab = labels + 4 * t;
+        if (!row_counts(lab)) continue;
+        const float ang = target_angle(lab, j);
+        acc += (double)(1.f - (pred[t * 16 + 2 * j] * cosf(ang) + pred[t * 16 + 2 * j + 1] * sinf(ang)));
+        ++c;
+    }
+    red[threadIdx.x] = acc;
+    if (j == 0) cnt[lane_row] = c;
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+        if (lane_row < s) {
+            red[threadIdx.x] += red[threadIdx.x + 8 * s];
+            if (j == 0) cnt[lane_row] += cnt[lane_row + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) out8[threadIdx.x] = cnt[0] > 0 ? (float)(red[threadIdx.x] / (double)cnt[0]) : 0.f;
+}
+
 // next[b] = decoded note from pred[b] (8 unit pairs), with the start time of prev[b] added to the start delta.
 __global__ void pos4d_next_kernel(const float* __restrict__ pred, long ld_pred, const float* __restrict__ prev,
                                   long ld_prev, float* __restrict__ next, long ld_next, int B) {
@@ -171,6 +202,12 @@ extern "C" int mgen_cos4d_fwd_bwd(const void* pairs, const float* labels, const 
         hipLaunchKernelGGL(cos4d_kernel<float>, dim3(nb), dim3(256), 0, stream, (const float*)pairs, labels,
                            inv_count, grad_scale, pred_out, row_loss, (float*)dpairs, T);
     return mgen_check_launch("mgen_cos4d_fwd_bwd");
+}
+
+extern "C" int mgen_cos4d_components(const float* pred, const float* labels, long T, float* out8, hipStream_t stream) {
+    MGEN_REQUIRE(pred && labels && out8 && T > 0, "mgen_cos4d_components: bad arguments");
+    hipLaunchKernelGGL(cos4d_components_kernel, dim3(1), dim3(1024), 0, stream, pred, labels, T, out8);
+    return mgen_check_launch("mgen_cos4d_components");
 }
 
 extern "C" int mgen_pos4d_next(const float* pred, long ld_pred, const float* prev, long ld_prev, float* next,

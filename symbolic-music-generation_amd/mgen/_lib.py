@@ -28,6 +28,7 @@ SIGNATURES = {
     "mgen_fill_rows": [P, P, L, I, P],
     "mgen_cos4d_count": [P, L, P, P, P],
     "mgen_cos4d_fwd_bwd": [P, P, P, F, P, P, P, L, I, P],
+    "mgen_cos4d_components": [P, P, L, P, P],
     "mgen_pos4d_next": [P, L, P, L, P, L, I, P],
     "mgen_attn_fwd": [P, P, P, P, P, L, L, L, L, I, I, I, I, I, F, P],
     "mgen_attn_bwd": [P, P, P, P, P, P, P, P, P, P, L, L, L, L, L, L, L, L, I, I, I, I, I, F, P],

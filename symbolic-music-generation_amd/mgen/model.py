@@ -477,6 +477,7 @@ class MidiLM(GenerationMixin, nn.Module):
         ops.gemm_any(xN, W, pairs, T, POS4D_HEAD_OUT, d, xN.stride(0), W.stride(0), POS4D_HEAD_OUT)
         pred = torch.empty(T, POS4D_HEAD_OUT, dtype=torch.float32, device=dev)
         self._last_pred = pred
+        self._last_labels4d = labels
         if labels is None:
             ops.cos4d_fwd_bwd(pairs, None, None, 1.0, pred, None, None)
             return None, None
@@ -496,6 +497,21 @@ class MidiLM(GenerationMixin, nn.Module):
             ops.gemm_any(dps, xN, grad_buf, POS4D_HEAD_OUT, d, T, POS4D_HEAD_OUT, xN.stride(0), d, True, True,
                          ops.OUT_F32_ACC)
         return loss, dxN
+
+    COMPONENT_LOSS_NAMES = ("loss/s_0", "loss/s_1", "loss/d_0", "loss/d_1", "loss/p_0", "loss/p_1", "loss/v_0",
+                            "loss/v_1")
+
+    def component_losses(self):
+        """The eight per-pair losses of the last labelled forward of the 4-D model, under the names the reference logs
+        them with (/root/reference/src/model/modeling.py:646-655): fine and coarse pair of start, duration, pitch,
+        velocity; fp32 [8] on the device. Their mean is the loss of that forward."""
+        if not self.cfg.pos4d:
+            raise ValueError("component_losses: only the 4-D position model has per-component losses")
+        if getattr(self, "_last_labels4d", None) is None:
+            raise RuntimeError("component_losses: no forward with labels has run")
+        out = torch.empty(8, dtype=torch.float32, device=self._last_pred.device)
+        ops.cos4d_components(self._last_pred, self._last_labels4d, out)
+        return dict(zip(self.COMPONENT_LOSS_NAMES, out.unbind(0)))
 
     def _head_grad_shape(self):
         return (POS4D_HEAD_OUT if self.cfg.pos4d else self.cfg.vocab_size, self.cfg.hidden_size)

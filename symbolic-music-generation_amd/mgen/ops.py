@@ -315,6 +315,12 @@ def cos4d_fwd_bwd(pairs, labels, inv_count, grad_scale, pred_out, row_loss, dpai
          _p(dpairs), T, int(pairs.dtype == torch.bfloat16), _stream())
 
 
+def cos4d_components(pred, labels, out8):
+    """out8[j] = mean over the counted rows of 1 - cos_sim of pair j (reference src/model/modeling.py:646-655)."""
+    _need_gpu(pred, labels, out8)
+    call("mgen_cos4d_components", _p(pred), _p(labels), labels.numel() // 4, _p(out8), _stream())
+
+
 def pos4d_next(pred, ld_pred, prev, ld_prev, nxt, ld_next, B):
     """pred/prev/nxt are raw device pointers (ints) to fp32 rows."""
     call("mgen_pos4d_next", pred, ld_pred, prev, ld_prev, nxt, ld_next, B, _stream())

@@ -169,5 +169,9 @@ class MidiQwenNew(_Wrapper):
         self.model = MidiLM(config or pos4d_decoder(), device=device, seed=seed)
 
     def forward(self, input_ids=None, attention_mask=None, labels=None, position_tensors=None):
-        return self.model(input_ids=input_ids, attention_mask=attention_mask, labels=labels,
-                          position_tensors=position_tensors)
+        out = self.model(input_ids=input_ids, attention_mask=attention_mask, labels=labels,
+                         position_tensors=position_tensors)
+        if labels is not None:   # the reference logs the eight per-pair losses from inside this forward
+            for name, value in self.model.component_losses().items():
+                self.log(name, value)
+        return out

@@ -155,6 +155,23 @@ def test_cosine_loss_and_gradient_fp32():
     assert float(out) == 0.0 and int(cnt) == 0 and float(dp.abs().max()) == 0.0
 
 
+def test_component_losses():
+    # the eight values the reference logs beside its loss, against the oracle on unit pairs and masked labels
+    from mgen import ops
+    g = torch.Generator().manual_seed(14)
+    for T in (1, 77, 5000):
+        pr = torch.randn(T, 8, 2, generator=g)
+        pred = pr / (torch.norm(pr, dim=-1, keepdim=True) + 1e-8)
+        lab = _labels(g, T) if T > 1 else _rows(g, T)
+        want = P.component_losses(pred, lab)
+        out = torch.empty(8, device="cuda")
+        ops.cos4d_components(pred.view(T, 16).cuda(), lab.cuda(), out)
+        np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+        assert abs(float(out.mean()) - float(P.cosine_loss(pred, lab))) < 1e-5
+    ops.cos4d_components(pred.view(T, 16).cuda(), torch.full((T, 4), -100.0).cuda(), out)
+    assert float(out.abs().max()) == 0.0
+
+
 def test_next_note_decoding():
     from mgen import ops
     g = torch.Generator().manual_seed(5)
@@ -230,6 +247,12 @@ def test_loss_and_grads_match_reference(tiny):
     with torch.no_grad():
         l2 = float(m(position_tensors=pos, labels=lab).loss)
     assert abs(l2 - loss) < 1e-6 * abs(loss)
+    comp = m.component_losses()
+    assert list(comp) == ["loss/s_0", "loss/s_1", "loss/d_0", "loss/d_1", "loss/p_0", "loss/p_1", "loss/v_0", "loss/v_1"]
+    cv = torch.stack(list(comp.values())).cpu()
+    assert abs(float(cv.mean()) - l2) < 1e-5 * abs(l2)
+    want = P.component_losses(m._last_pred.view(2, 128, 8, 2).cpu(), lab.cpu())
+    np.testing.assert_allclose(cv.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
     # all rows masked: zero loss, zero gradients
     m.zero_grad()
     o = m(position_tensors=pos, labels=torch.full_like(lab, -100.0))

@@ -108,5 +108,9 @@ def test_pos4d_wrapper(tmp_path):
         sched.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
+    # the eight per-pair losses the reference logs from its forward; their mean is the logged loss
+    names = ["loss/s_0", "loss/s_1", "loss/d_0", "loss/d_1", "loss/p_0", "loss/p_1", "loss/v_0", "loss/v_1"]
+    comp = torch.stack([m.logged[n] for n in names])
+    assert abs(float(comp.mean()) - float(m.logged["train_loss"])) < 1e-5
     rows = m.model.generate_music(pos[:1, :1].cuda(), 5)
     assert tuple(rows.shape) == (1, 6, 4)

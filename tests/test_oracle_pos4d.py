@@ -40,6 +40,17 @@ def test_fp32_loss_pred_grads(gold):
     assert abs(float(gn) - float(g["fp32_grad_norm"])) < 1e-4 * float(g["fp32_grad_norm"])
 
 
+def test_component_losses_average_to_the_reference_loss(gold):
+    # every column has the same number of rows, so the reference's loss is the mean of the eight values it logs
+    g, p = gold
+    lab = torch.from_numpy(g["labels"])
+    pred = torch.from_numpy(g["fp32_pred"])
+    comp = P.component_losses(pred, lab)
+    assert comp.shape == (8,)
+    assert abs(float(comp.mean()) - float(g["fp32_loss"])) < 1e-5 * abs(float(g["fp32_loss"]))
+    assert float(P.component_losses(pred, torch.full_like(lab, -100.0)).abs().max()) == 0.0
+
+
 def test_all_masked_loss_is_zero(gold):
     g, p = gold
     pos, lab = torch.from_numpy(g["position_tensors"]), torch.from_numpy(g["labels"])
