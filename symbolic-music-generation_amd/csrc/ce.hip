@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NT) void ce_row_kernel(bf16* __restrict__ logits, c
     u32x4 v[NV];
     auto load_vec = [&](const bf16* row, int j) {
         const int i = tid + j * NT;
-        if (i < nvec) v[j] = *reinterpret_cast<const u32x4*>(row + (long)i * 8);
+        if (i < nvec) v[j] = ld_stream(reinterpret_cast<const u32x4*>(row + (long)i * 8));
         else v[j] = u32x4{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};   // -inf: no weight in max or sum
     };
     long r = blockIdx.x;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NT) void ce_row_kernel(bf16* __restrict__ logits, c
                         }
                 }
                 // (columns past V inside the last vector were set to -inf: their gradient is exp2(-inf) = 0)
-                *reinterpret_cast<u32x4*>(row + (long)i * 8) = o;
+                st_stream(reinterpret_cast<u32x4*>(row + (long)i * 8), o);
             }
             if (has_next) load_vec(row_next, j);
         }

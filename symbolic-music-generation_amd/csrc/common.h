@@ -15,6 +15,27 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+// Streaming accesses of the element-wise kernels: data that is read once or written for a later kernel carries the
+// non-temporal hint, so it does not displace what other kernels keep in L2. MGEN_STREAM_NT=0 builds plain accesses
+// (same-machine comparisons).
+#ifndef MGEN_STREAM_NT
+#define MGEN_STREAM_NT 1
+#endif
+template <typename V> __device__ __forceinline__ V ld_stream(const V* p) {
+#if MGEN_STREAM_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename V> __device__ __forceinline__ void st_stream(V* p, V v) {
+#if MGEN_STREAM_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 #define MGEN_WAVE 64
 
 // error codes returned by the C-ABI

@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16* __restrict
         for (int u = 0; u < U; ++u) {
             const int key = base + u * RPI + grp;
             const int ck = min(key, k_end - 1);
-            kk[u] = *reinterpret_cast<const bf16x8*>(kb + (long)ck * D);
-            vv[u] = *reinterpret_cast<const bf16x8*>(vb + (long)ck * D);
+            kk[u] = ld_stream(reinterpret_cast<const bf16x8*>(kb + (long)ck * D));
+            vv[u] = ld_stream(reinterpret_cast<const bf16x8*>(vb + (long)ck * D));
         }
         float mx = m;
 #pragma unroll

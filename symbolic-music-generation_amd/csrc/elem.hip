@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict_
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         const long t = i / vpr;
         const int c = (int)(i % vpr) * 8;
-        const bf16x8 g = *reinterpret_cast<const bf16x8*>(gu + t * ldgu + c);
-        const bf16x8 u = *reinterpret_cast<const bf16x8*>(gu + t * ldgu + I + c);
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dact + t * lddact + c);
+        const bf16x8 g = ld_stream(reinterpret_cast<const bf16x8*>(gu + t * ldgu + c));
+        const bf16x8 u = ld_stream(reinterpret_cast<const bf16x8*>(gu + t * ldgu + I + c));
+        const bf16x8 d = ld_stream(reinterpret_cast<const bf16x8*>(dact + t * lddact + c));
         bf16x8 dg, du;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16* __restrict_
             du[e] = (bf16)(df * silu);
             dg[e] = (bf16)(df * uf * (sg * (1.f + gf * (1.f - sg))));
         }
-        *reinterpret_cast<bf16x8*>(dgu + t * lddgu + c) = dg;
-        *reinterpret_cast<bf16x8*>(dgu + t * lddgu + I + c) = du;
+        st_stream(reinterpret_cast<bf16x8*>(dgu + t * lddgu + c), dg);
+        st_stream(reinterpret_cast<bf16x8*>(dgu + t * lddgu + I + c), du);
     }
 }
 

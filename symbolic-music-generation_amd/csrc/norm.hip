@@ -15,8 +15,8 @@ namespace {
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
-    static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-    static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    static __device__ __forceinline__ f32x4 load(const float* p) { return ld_stream(reinterpret_cast<const f32x4*>(p)); }
+    static __device__ __forceinline__ void store(float* p, f32x4 v) { st_stream(reinterpret_cast<f32x4*>(p), v); }
 };
 template <> struct Vec4<bf16> {
     static __device__ __forceinline__ f32x4 load(const bf16* p) {

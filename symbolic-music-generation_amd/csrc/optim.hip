@@ -59,10 +59,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float step = a.lr * a.inv_bc1;
     const float decay = 1.f - a.lr * a.wd;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4 pv = *reinterpret_cast<const f32x4*>(p + 4 * i);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * i) * coef;
-        f32x4 mv = *reinterpret_cast<const f32x4*>(m + 4 * i);
-        f32x4 vv = *reinterpret_cast<const f32x4*>(v + 4 * i);
+        f32x4 pv = ld_stream(reinterpret_cast<const f32x4*>(p + 4 * i));
+        const f32x4 gv = ld_stream(reinterpret_cast<const f32x4*>(g + 4 * i)) * coef;
+        f32x4 mv = ld_stream(reinterpret_cast<const f32x4*>(m + 4 * i));
+        f32x4 vv = ld_stream(reinterpret_cast<const f32x4*>(v + 4 * i));
         bf16x4 sh;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -73,10 +73,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             pv[e] -= step * (mv[e] / denom);
             sh[e] = (bf16)pv[e];
         }
-        *reinterpret_cast<f32x4*>(p + 4 * i) = pv;
-        *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
-        *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
-        if (shadow) *reinterpret_cast<bf16x4*>(shadow + 4 * i) = sh;
+        st_stream(reinterpret_cast<f32x4*>(p + 4 * i), pv);
+        st_stream(reinterpret_cast<f32x4*>(m + 4 * i), mv);
+        st_stream(reinterpret_cast<f32x4*>(v + 4 * i), vv);
+        if (shadow) st_stream(reinterpret_cast<bf16x4*>(shadow + 4 * i), sh);
     }
 }
 

@@ -46,7 +46,7 @@ __global__ void rope4d_table_kernel(const float* __restrict__ pos4, const float*
 
 template <typename IoT> __device__ __forceinline__ void load8(const IoT* p, float* x) {
     if (sizeof(IoT) == 2) {
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+        bf16x8 v = ld_stream(reinterpret_cast<const bf16x8*>(p));
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = (float)v[e];
     } else {
@@ -59,7 +59,7 @@ template <typename IoT> __device__ __forceinline__ void store8(IoT* p, const flo
         bf16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (bf16)x[e];
-        *reinterpret_cast<bf16x8*>(p) = v;
+        st_stream(reinterpret_cast<bf16x8*>(p), v);
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) p[e] = (IoT)x[e];

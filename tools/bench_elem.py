@@ -60,3 +60,13 @@ timeit("swiglu_fwd", lambda: ops.swiglu_fwd(gu, act), T * I * 2 * 3)
 dact = torch.randn(T, I, device=dev).to(bf)
 dgu = torch.empty(T, 2 * I, dtype=bf, device=dev)
 timeit("swiglu_bwd", lambda: ops.swiglu_bwd(gu, dact, dgu), T * I * 2 * 5)
+# cross entropy with the gradient written in place: 4096 rows of the 151 936-entry vocabulary
+V, R = 151936, 4096
+logits = torch.randn(R, V, device=dev).to(bf)
+labels = torch.randint(0, V, (R + 1,), device=dev)
+invc = torch.full((1,), 1.0 / R, device=dev)
+row_loss = torch.empty(R, device=dev)
+from mgen._lib import call  # noqa: E402
+timeit("ce_fwd_bwd", lambda: call("mgen_ce_fwd_bwd", logits.data_ptr(), labels.data_ptr(), 0, R, V, V, R + 1, -100,
+                                  invc.data_ptr(), 1.0, row_loss.data_ptr(), None, 1, 1,
+                                  torch.cuda.current_stream().cuda_stream), R * V * 2 * 2, n=5)
