@@ -13,7 +13,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 V = int(sys.argv[2]) if len(sys.argv) > 2 else 151936
 ld = (V + 7) // 8 * 8
 g = torch.Generator(device="cuda").manual_seed(0)
-logits = (torch.randn(B, ld, device="cuda", generator=g) * 3.0).bfloat16()
+SCALE = float(os.environ.get("SAMPLER_LOGIT_STD", "3.0"))   # 0.05 ~ a random-init model: nearly uniform rows
+logits = (torch.randn(B, ld, device="cuda", generator=g) * SCALE).bfloat16()
 out = torch.empty(B, dtype=torch.int64, device="cuda")
 for name, kw in (("greedy", dict(do_sample=False, temperature=1.0, top_k=0, top_p=1.0)),
                  ("T0.97 p0.95", dict(do_sample=True, temperature=0.97, top_k=0, top_p=0.95)),
