@@ -89,8 +89,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* 
     }
     for (long row = wave0; row < T; row += nwaves) {
         const float r = rstd[row];
-        f32x4 xh[VPL], gv[VPL];
+        f32x4 xh[VPL], gv[VPL], old[VPL];
         float dot = 0.f;
+        // (the running gradient is requested together with the other two streams, not after the row reduction:
+        // 120 -> 111 us at 65536 x 512; a second row per wave in flight added nothing)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            old[i] = (accumulate && c < d) ? Vec4<float>::load(dres + row * d + c) : f32x4{0, 0, 0, 0};
+        }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (i * 64 + lane) * 4;
@@ -110,9 +117,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* 
         for (int i = 0; i < VPL; ++i) {
             const int c = (i * 64 + lane) * 4;
             if (c < d) {
-                f32x4 dx = (gv[i] - xh[i] * dot) * r;
+                const f32x4 dx = (gv[i] - xh[i] * dot) * r + old[i];
                 float* p = dres + row * d + c;
-                if (accumulate) dx += Vec4<float>::load(p);
                 Vec4<float>::store(p, dx);
                 if (dres_lp) Vec4<DyT>::store(dres_lp + row * d + c, dx);
             }

@@ -122,6 +122,12 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const IoT* __restrict_
             const IoT* src = in + t * ld_in + (long)hh * D;
             load8(src + o1, a);
             load8(src + o2, a + 8);
+            float x[16];   // backward with a norm: the forward input, requested together with the gradient
+            if (!FWD && nrm) {
+                const IoT* rsrc = raw + t * ld_raw + (long)hh * D;
+                load8(rsrc + o1, x);
+                load8(rsrc + o2, x + 8);
+            }
             float o[16];
             if (FWD) {
                 if (nrm) {
@@ -157,10 +163,6 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const IoT* __restrict_
                     dy[e] = second ? (a[e] * c[ci] - a[pe] * s[ci]) : (a[e] * c[ci] + a[pe] * s[ci]);
                 }
                 if (nrm) {
-                    float x[16];
-                    const IoT* rsrc = raw + t * ld_raw + (long)hh * D;
-                    load8(rsrc + o1, x);
-                    load8(rsrc + o2, x + 8);
                     float ss = 0.f;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) ss += x[e] * x[e];
