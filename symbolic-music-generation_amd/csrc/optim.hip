@@ -58,25 +58,41 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const long n4 = n / 4;
     const float step = a.lr * a.inv_bc1;
     const float decay = 1.f - a.lr * a.wd;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4 pv = ld_stream(reinterpret_cast<const f32x4*>(p + 4 * i));
-        const f32x4 gv = ld_stream(reinterpret_cast<const f32x4*>(g + 4 * i)) * coef;
-        f32x4 mv = ld_stream(reinterpret_cast<const f32x4*>(m + 4 * i));
-        f32x4 vv = ld_stream(reinterpret_cast<const f32x4*>(v + 4 * i));
-        bf16x4 sh;
+    // a workgroup owns contiguous spans of 4 x 4 KiB per stream and requests all 16 vectors before the arithmetic
+    constexpr int UN = 4;
+    const long per = 256L * UN;
+    for (long b = blockIdx.x; b * per < n4; b += gridDim.x) {
+        f32x4 pv[UN], gv[UN], mv[UN], vv[UN];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            pv[e] *= decay;
-            mv[e] = mv[e] + (gv[e] - mv[e]) * (1.f - a.beta1);
-            vv[e] = vv[e] * a.beta2 + (1.f - a.beta2) * gv[e] * gv[e];
-            const float denom = sqrtf(vv[e]) * a.inv_sqrt_bc2 + a.eps;
-            pv[e] -= step * (mv[e] / denom);
-            sh[e] = (bf16)pv[e];
+        for (int u = 0; u < UN; ++u) {
+            const long i = b * per + u * 256 + threadIdx.x;
+            if (i < n4) {
+                pv[u] = ld_stream(reinterpret_cast<const f32x4*>(p + 4 * i));
+                gv[u] = ld_stream(reinterpret_cast<const f32x4*>(g + 4 * i));
+                mv[u] = ld_stream(reinterpret_cast<const f32x4*>(m + 4 * i));
+                vv[u] = ld_stream(reinterpret_cast<const f32x4*>(v + 4 * i));
+            }
         }
-        st_stream(reinterpret_cast<f32x4*>(p + 4 * i), pv);
-        st_stream(reinterpret_cast<f32x4*>(m + 4 * i), mv);
-        st_stream(reinterpret_cast<f32x4*>(v + 4 * i), vv);
-        if (shadow) st_stream(reinterpret_cast<bf16x4*>(shadow + 4 * i), sh);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long i = b * per + u * 256 + threadIdx.x;
+            if (i >= n4) continue;
+            bf16x4 sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = gv[u][e] * coef;
+                pv[u][e] *= decay;
+                mv[u][e] = mv[u][e] + (ge - mv[u][e]) * (1.f - a.beta1);
+                vv[u][e] = vv[u][e] * a.beta2 + (1.f - a.beta2) * ge * ge;
+                const float denom = sqrtf(vv[u][e]) * a.inv_sqrt_bc2 + a.eps;
+                pv[u][e] -= step * (mv[u][e] / denom);
+                sh[e] = (bf16)pv[u][e];
+            }
+            st_stream(reinterpret_cast<f32x4*>(p + 4 * i), pv[u]);
+            st_stream(reinterpret_cast<f32x4*>(m + 4 * i), mv[u]);
+            st_stream(reinterpret_cast<f32x4*>(v + 4 * i), vv[u]);
+            if (shadow) st_stream(reinterpret_cast<bf16x4*>(shadow + 4 * i), sh);
+        }
     }
 }
 
@@ -191,8 +207,8 @@ extern "C" int mgen_adamw_step(float* param, const float* grad, float* exp_avg, 
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd;
     a.inv_bc1 = (float)(1.0 / (1.0 - pow((double)beta1, (double)step)));
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)beta2, (double)step)));
-    long nb = (n / 4 + 255) / 256;
-    if (nb > 4096) nb = 4096;
+    long nb = (n / 4 + 1023) / 1024;
+    if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq,
                        (bf16*)shadow_bf16, n, clip, a);
     return mgen_check_launch("mgen_adamw_step");

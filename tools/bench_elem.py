@@ -70,3 +70,9 @@ from mgen._lib import call  # noqa: E402
 timeit("ce_fwd_bwd", lambda: call("mgen_ce_fwd_bwd", logits.data_ptr(), labels.data_ptr(), 0, R, V, V, R + 1, -100,
                                   invc.data_ptr(), 1.0, row_loss.data_ptr(), None, 1, 1,
                                   torch.cuda.current_stream().cuda_stream), R * V * 2 * 2, n=5)
+# AdamW over the default decoder's 151 M parameters (fp32 p, g, m, v + bf16 shadow)
+NP = 151_191_552
+pp, gg, mm, vv = (torch.randn(NP, device=dev) * 0.01 for _ in range(4))
+vv.abs_()
+sh = torch.empty(NP, dtype=bf, device=dev)
+timeit("adamw", lambda: ops.adamw_step(pp, gg, mm, vv, sh, None, 1e-4, 0.9, 0.999, 1e-8, 0.01, 3), NP * 30, n=5)
