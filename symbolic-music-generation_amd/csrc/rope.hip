@@ -111,23 +111,24 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const IoT* __restrict_
                 c[e] = v[0]; s[e] = v[1]; c[e + 1] = v[2]; s[e + 1] = v[3];
             }
         }
-        // gridDim.y > 1 (few tokens: decode) spreads the heads of a token over workgroups
-        for (int hh = blockIdx.y; hh < NH; hh += gridDim.y) {
-            const bool isq = hh < HQ;
-            const bool isk = !isq && hh < HQ + HK;
-            const bool nrm = norm && (isq || isk);
-            IoT* outp = isq ? qout + t * ld_q + (long)hh * D
-                            : (isk ? kout + t * ld_k + (long)(hh - HQ) * D : vout + t * ld_v + (long)(hh - HQ - HK) * D);
-            float a[16];
+        // the rows of head hh: a = input (backward: d(out)), x = forward input (backward with a norm)
+        auto request = [&](int hh, float (&a)[16], float (&x)[16]) {
+            const bool nrm = norm && hh < HQ + HK;
             const IoT* src = in + t * ld_in + (long)hh * D;
             load8(src + o1, a);
             load8(src + o2, a + 8);
-            float x[16];   // backward with a norm: the forward input, requested together with the gradient
             if (!FWD && nrm) {
                 const IoT* rsrc = raw + t * ld_raw + (long)hh * D;
                 load8(rsrc + o1, x);
                 load8(rsrc + o2, x + 8);
             }
+        };
+        auto finish = [&](int hh, float (&a)[16], float (&x)[16]) {
+            const bool isq = hh < HQ;
+            const bool isk = !isq && hh < HQ + HK;
+            const bool nrm = norm && (isq || isk);
+            IoT* outp = isq ? qout + t * ld_q + (long)hh * D
+                            : (isk ? kout + t * ld_k + (long)(hh - HQ) * D : vout + t * ld_v + (long)(hh - HQ - HK) * D);
             float o[16];
             if (FWD) {
                 if (nrm) {
@@ -188,6 +189,19 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const IoT* __restrict_
             }
             store8(outp + o1, o);
             store8(outp + o2, o + 8);
+        };
+        // gridDim.y > 1 (few tokens: decode) spreads the heads of a token over workgroups. Several heads per
+        // iteration: the rows of all of them are requested before the first one's row reduction.
+        constexpr int NHI = 2;   // (forward 132 -> 110 us; four at a time: 120)
+        const int hstep = gridDim.y;
+        for (int hh = blockIdx.y; hh < NH; hh += NHI * hstep) {
+            float a[NHI][16], x[NHI][16];
+#pragma unroll
+            for (int q = 0; q < NHI; ++q)
+                if (hh + q * hstep < NH) request(hh + q * hstep, a[q], x[q]);
+#pragma unroll
+            for (int q = 0; q < NHI; ++q)
+                if (hh + q * hstep < NH) finish(hh + q * hstep, a[q], x[q]);
         }
     }
     if (!FWD && norm) {
