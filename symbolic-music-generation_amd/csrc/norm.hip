@@ -43,25 +43,34 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
         const int c = (i * 64 + lane) * 4;
         wv[i] = c < d ? Vec4<float>::load(w + c) : f32x4{0, 0, 0, 0};
     }
-    for (long row = wave0; row < T; row += nwaves) {
-        const float* xr = x + row * d;
-        f32x4 xv[VPL];
-        float ss = 0.f;
+    // Two rows per wave and iteration, both requested before the first row reduction. The residual stream was
+    // written by the kernel before this one and is read again by the next residual projection: plain loads.
+    for (long row0 = wave0; row0 < T; row0 += 2 * nwaves) {
+        const long row1 = row0 + nwaves;
+        f32x4 xa[VPL], xb[VPL];
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int c = (i * 64 + lane) * 4;
-            xv[i] = c < d ? Vec4<float>::load(xr + c) : f32x4{0, 0, 0, 0};
-            ss += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
+            xa[i] = c < d ? *reinterpret_cast<const f32x4*>(x + row0 * d + c) : f32x4{0, 0, 0, 0};
+            xb[i] = (c < d && row1 < T) ? *reinterpret_cast<const f32x4*>(x + row1 * d + c) : f32x4{0, 0, 0, 0};
         }
-        ss = wave_sum(ss);
-        const float r = rsqrtf(ss / (float)d + eps);
-        if (lane == 0 && rstd_out) rstd_out[row] = r;
-        OutT* yr = y + row * d;
+        auto finish = [&](long row, const f32x4 (&xv)[VPL]) {
+            float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            if (c < d) Vec4<OutT>::store(yr + c, wv[i] * (xv[i] * r));
-        }
+            for (int i = 0; i < VPL; ++i)
+                ss += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
+            ss = wave_sum(ss);
+            const float r = rsqrtf(ss / (float)d + eps);
+            if (lane == 0 && rstd_out) rstd_out[row] = r;
+            OutT* yr = y + row * d;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < d) Vec4<OutT>::store(yr + c, wv[i] * (xv[i] * r));
+            }
+        };
+        finish(row0, xa);
+        if (row1 < T) finish(row1, xb);
     }
 }
 
