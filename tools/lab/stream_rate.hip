@@ -118,6 +118,8 @@ int main() {
     RUN("blockcopy plain un4", 2.0 * bytes, copy_block_kernel<0, 4><<<g, 256>>>(a, b, n));
     RUN("blockcopy nt both un4", 2.0 * bytes, copy_block_kernel<3, 4><<<g, 256>>>(a, b, n));
     RUN("blockcopy nt both un8", 2.0 * bytes, copy_block_kernel<3, 8><<<g, 256>>>(a, b, n));
+    RUN("blockcopy in-place plain un4", 2.0 * bytes, copy_block_kernel<0, 4><<<g, 256>>>(a, a, n));
+    RUN("blockcopy in-place nt both un4", 2.0 * bytes, copy_block_kernel<3, 4><<<g, 256>>>(a, a, n));
     RUN("in-place plain un4", 2.0 * bytes, copy_kernel<0, 4><<<g, 256>>>(a, a, n));
     RUN("in-place nt both un4", 2.0 * bytes, copy_kernel<3, 4><<<g, 256>>>(a, a, n));
     RUN("read plain un4", 1.0 * bytes, read_kernel<0, 4><<<g, 256>>>(a, o, n));
