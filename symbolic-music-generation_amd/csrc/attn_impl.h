@@ -682,19 +682,28 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16* __restrict_
     constexpr int LPR = HD / 8;
     const long nrows = (long)B * S * H;
     const int sub = threadIdx.x % LPR;
-    for (long row = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; row < nrows;
-         row += (long)gridDim.x * (256 / LPR)) {
-        const long tok = row / H;
-        const int h = (int)(row % H);
-        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(O + tok * so + (long)h * HD + sub * 8);
-        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dO + tok * sdo + (long)h * HD + sub * 8);
-        float s = 0.f;
+    // two rows per lane group and iteration, both requested before the first reduction
+    const long stride = (long)gridDim.x * (256 / LPR);
+    for (long row0 = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR; row0 < nrows; row0 += 2 * stride) {
+        const long row1 = row0 + stride;
+        const bool two = row1 < nrows;
+        const long tok0 = row0 / H, tok1 = two ? row1 / H : tok0;
+        const int h0 = (int)(row0 % H), h1 = two ? (int)(row1 % H) : h0;
+        const bf16x8 ov0 = ld_stream(reinterpret_cast<const bf16x8*>(O + tok0 * so + (long)h0 * HD + sub * 8));
+        const bf16x8 dv0 = *reinterpret_cast<const bf16x8*>(dO + tok0 * sdo + (long)h0 * HD + sub * 8);
+        const bf16x8 ov1 = ld_stream(reinterpret_cast<const bf16x8*>(O + tok1 * so + (long)h1 * HD + sub * 8));
+        const bf16x8 dv1 = *reinterpret_cast<const bf16x8*>(dO + tok1 * sdo + (long)h1 * HD + sub * 8);
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)ov[e] * (float)dv[e];
-        s = group_sum<LPR>(s);
+        for (int e = 0; e < 8; ++e) {
+            s0 += (float)ov0[e] * (float)dv0[e];
+            s1 += (float)ov1[e] * (float)dv1[e];
+        }
+        s0 = group_sum<LPR>(s0);
+        s1 = group_sum<LPR>(s1);
         if (sub == 0) {
-            const long b = tok / S, q = tok % S;
-            delta[(b * H + h) * S + q] = s;
+            delta[((tok0 / S) * H + h0) * S + tok0 % S] = s0;
+            if (two) delta[((tok1 / S) * H + h1) * S + tok1 % S] = s1;
         }
     }
 }
