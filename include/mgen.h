@@ -86,6 +86,17 @@ int mgen_qknorm_rope_bwd(const void* dqk, long ld_in, void* dq_raw, void* dk_raw
                          const void* raw_qkv, long ld_raw, const float* wq, const float* wk, float* dwq, float* dwk,
                          const float* cos_sin, const int* pos, int S, long T, int HQ, int HK, int D, float eps,
                          int is_bf16, mgen_stream_t stream);
+/* The same two with adjacent pairs (elements 2i and 2i+1 of a head rotate by the angle of frequency i; the pairing of
+ * GPT-J-style blocks, which the Aria checkpoint the reference loads at src/model/model.py:191 is recalled to use) and
+ * the same position-indexed table. Equal to the split-half form on q/k projections whose output rows are permuted
+ * [0, 2, 4, ..., 1, 3, 5, ...] within each head. */
+int mgen_qknorm_rope_il_fwd(const void* qkv, long ld_in, void* qout, void* kout, long ld_q, long ld_k, const float* wq,
+                            const float* wk, const float* cos_sin, const int* pos, int S, long T, int HQ, int HK, int D,
+                            float eps, int is_bf16, mgen_stream_t stream);
+int mgen_qknorm_rope_il_bwd(const void* dqk, long ld_in, void* dq_raw, void* dk_raw, long ld_q, long ld_k,
+                            const void* raw_qkv, long ld_raw, const float* wq, const float* wk, float* dwq, float* dwk,
+                            const float* cos_sin, const int* pos, int S, long T, int HQ, int HK, int D, float eps,
+                            int is_bf16, mgen_stream_t stream);
 
 /* ---- 4-D position model: adjacent-pair rotary embedding from continuous note coordinates ------------------------
  * Replaces Qwen3Model.rot_pos_emb (reference src/model/modeling.py:498-545): cos_sin[t][a*(D/8)+j] =

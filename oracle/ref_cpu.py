@@ -56,6 +56,7 @@ class LMConfig:
     rope_theta: float = 1e6
     tie_word_embeddings: bool = True
     qk_norm: bool = True          # Qwen3: per-head RMSNorm on q and k; Llama: none
+    rope_interleaved: bool = False  # rotation pairs (2i, 2i+1) instead of the split-half pairs (i, i + Dh/2)
     bos_token_id: int = 1
     eos_token_id: int = 2
     pad_token_id: int = 0
@@ -127,6 +128,18 @@ def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.T
     return x * c + rotate_half(x) * s
 
 
+def apply_rope_interleaved(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """Adjacent-pair form: elements 2i, 2i+1 rotate by the angle of frequency i (cos/sin as from rope_cos_sin, whose
+    first half holds the Dh/2 frequencies). The same rotation as apply_rope on head dims permuted
+    [0, 2, 4, ..., 1, 3, 5, ...]; the pair arithmetic is that of the 4-D model's rotation
+    (/root/reference/src/model/modeling.py:143-180)."""
+    h = x.shape[-1] // 2
+    c = cos[..., :h].unsqueeze(1).to(x.dtype)
+    s = sin[..., :h].unsqueeze(1).to(x.dtype)
+    x1, x2 = x[..., 0::2], x[..., 1::2]
+    return torch.stack((x1 * c - x2 * s, x2 * c + x1 * s), dim=-1).flatten(-2)
+
+
 def causal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float,
                      key_padding_mask: Optional[torch.Tensor] = None, q_offset: int = 0,
                      drop_keep: Optional[torch.Tensor] = None, drop_p: float = 0.0) -> torch.Tensor:
@@ -190,8 +203,9 @@ def decoder_layer(h: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, cfg: LM
         q = rmsnorm(q, p[pre + "self_attn.q_norm.weight"], cfg.rms_norm_eps)
         k = rmsnorm(k, p[pre + "self_attn.k_norm.weight"], cfg.rms_norm_eps)
     q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
-    q = apply_rope(q, cos, sin)
-    k = apply_rope(k, cos, sin)
+    rope = apply_rope_interleaved if cfg.rope_interleaved else apply_rope
+    q = rope(q, cos, sin)
+    k = rope(k, cos, sin)
     if mode == "bf16":
         q, k, v = _bf(q), _bf(k), _bf(v)
     q_offset = 0

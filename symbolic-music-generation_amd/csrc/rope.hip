@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const IoT* __restrict_
                                                           const float* __restrict__ cs, const int* __restrict__ pos,
                                                           int S, long T, int HQ, int HK, int HV, float eps,
                                                           const IoT* __restrict__ raw, long ld_raw,
-                                                          float* __restrict__ dwq, float* __restrict__ dwk) {
+                                                          float* __restrict__ dwq, float* __restrict__ dwk,
+                                                          int per_token) {
     constexpr int LPR = D / 16;            // lanes per token
     constexpr int TPB = 256 / LPR;         // tokens per block per iteration
     const int sub = threadIdx.x % LPR;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const IoT* __restrict_
     for (long t = (long)blockIdx.x * TPB + tib; t < T; t += (long)gridDim.x * TPB) {
         float c[8], s[8];
         {
-            const long trow = IL ? t : (long)(pos ? pos[t] : (int)(t % S));
+            const long trow = per_token ? t : (long)(pos ? pos[t] : (int)(t % S));   // table row: the token's own, or its position's
             const float* cp = cs + (trow * (D / 2) + 8 * sub) * 2;
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
@@ -251,7 +252,8 @@ template <bool FWD, bool IL>
 static int qknorm_rope_launch(const void* in, long ld_in, void* qout, void* kout, void* vout, long ld_q, long ld_k,
                               long ld_v, const float* wq, const float* wk, const float* cs, const int* pos, int S,
                               long T, int HQ, int HK, int HV, int D, float eps, const void* raw, long ld_raw,
-                              float* dwq, float* dwk, int is_bf16, hipStream_t stream, const char* what) {
+                              float* dwq, float* dwk, int is_bf16, hipStream_t stream, const char* what,
+                              int per_token = IL ? 1 : 0) {
     const int tpb = 256 / (D / 16);
     long nb = (T + tpb - 1) / tpb;
     if (nb > 4096) nb = 4096;
@@ -260,7 +262,7 @@ static int qknorm_rope_launch(const void* in, long ld_in, void* qout, void* kout
 #define LAUNCH(DD, TT)                                                                                         \
     hipLaunchKernelGGL((qknorm_rope_kernel<DD, TT, FWD, IL>), dim3((unsigned)nb, ny), dim3(256), 0, stream,    \
                        (const TT*)in, ld_in, (TT*)qout, (TT*)kout, (TT*)vout, ld_q, ld_k, ld_v, wq, wk, cs,    \
-                       pos, S, T, HQ, HK, HV, eps, (const TT*)raw, ld_raw, dwq, dwk)
+                       pos, S, T, HQ, HK, HV, eps, (const TT*)raw, ld_raw, dwq, dwk, per_token)
     if (D == 128 && is_bf16) LAUNCH(128, bf16);
     else if (D == 128) LAUNCH(128, float);
     else if (D == 64 && is_bf16) LAUNCH(64, bf16);
@@ -296,6 +298,38 @@ extern "C" int mgen_qknorm_rope_bwd(const void* dqk, long ld_in, void* dq_raw, v
     return qknorm_rope_launch<false, false>(dqk, ld_in, dq_raw, dk_raw, nullptr, ld_q, ld_k, 0, wq, wk, cos_sin, pos,
                                             S, T, HQ, HK, 0, D, eps, raw_qkv, ld_raw, dwq, dwk, is_bf16, stream,
                                             "mgen_qknorm_rope_bwd");
+}
+
+// The same two with ADJACENT pairs (elements 2i, 2i+1 rotate by the angle of frequency i: the GPT-J / "interleaved"
+// pairing) and the position-indexed table of mgen_rope_table. Equal to the split-half form on q/k projections whose
+// output rows are permuted [0, 2, 4, ..., 1, 3, 5, ...] within each head.
+extern "C" int mgen_qknorm_rope_il_fwd(const void* qkv, long ld_in, void* qout, void* kout, long ld_q, long ld_k,
+                                       const float* wq, const float* wk, const float* cos_sin, const int* pos, int S,
+                                       long T, int HQ, int HK, int D, float eps, int is_bf16, hipStream_t stream) {
+    MGEN_REQUIRE(qkv && qout && kout && cos_sin, "mgen_qknorm_rope_il_fwd: null pointer");
+    MGEN_REQUIRE(D == 128 || D == 64, "mgen_qknorm_rope_il_fwd: head_dim must be 64 or 128 (got %d)", D);
+    MGEN_REQUIRE((wq == nullptr) == (wk == nullptr), "mgen_qknorm_rope_il_fwd: wq and wk must both be given or both null");
+    MGEN_REQUIRE(ld_in % 8 == 0 && ld_q % 8 == 0 && ld_k % 8 == 0, "mgen_qknorm_rope_il_fwd: strides must be multiples of 8");
+    MGEN_REQUIRE(T > 0 && S > 0 && HQ > 0 && HK > 0, "mgen_qknorm_rope_il_fwd: bad sizes");
+    return qknorm_rope_launch<true, true>(qkv, ld_in, qout, kout, nullptr, ld_q, ld_k, 0, wq, wk, cos_sin, pos, S, T,
+                                          HQ, HK, 0, D, eps, nullptr, 0, nullptr, nullptr, is_bf16, stream,
+                                          "mgen_qknorm_rope_il_fwd", 0);
+}
+
+extern "C" int mgen_qknorm_rope_il_bwd(const void* dqk, long ld_in, void* dq_raw, void* dk_raw, long ld_q, long ld_k,
+                                       const void* raw_qkv, long ld_raw, const float* wq, const float* wk, float* dwq,
+                                       float* dwk, const float* cos_sin, const int* pos, int S, long T, int HQ, int HK,
+                                       int D, float eps, int is_bf16, hipStream_t stream) {
+    MGEN_REQUIRE(dqk && dq_raw && dk_raw && cos_sin, "mgen_qknorm_rope_il_bwd: null pointer");
+    MGEN_REQUIRE(D == 128 || D == 64, "mgen_qknorm_rope_il_bwd: head_dim must be 64 or 128 (got %d)", D);
+    MGEN_REQUIRE((wq == nullptr) == (wk == nullptr), "mgen_qknorm_rope_il_bwd: wq and wk must both be given or both null");
+    if (wq) MGEN_REQUIRE(raw_qkv && dwq && dwk, "mgen_qknorm_rope_il_bwd: norm backward needs raw_qkv, dwq, dwk");
+    MGEN_REQUIRE(ld_in % 8 == 0 && ld_q % 8 == 0 && ld_k % 8 == 0 && ld_raw % 8 == 0,
+                 "mgen_qknorm_rope_il_bwd: strides must be multiples of 8");
+    MGEN_REQUIRE(T > 0 && S > 0 && HQ > 0 && HK > 0, "mgen_qknorm_rope_il_bwd: bad sizes");
+    return qknorm_rope_launch<false, true>(dqk, ld_in, dq_raw, dk_raw, nullptr, ld_q, ld_k, 0, wq, wk, cos_sin, pos,
+                                           S, T, HQ, HK, 0, D, eps, raw_qkv, ld_raw, dwq, dwk, is_bf16, stream,
+                                           "mgen_qknorm_rope_il_bwd", 0);
 }
 
 // Adjacent-pair rotation with a per-token table [T, D/2, 2]. Head counts may be zero: with HQ = HK = 0 the call is a

@@ -22,6 +22,8 @@ SIGNATURES = {
     "mgen_rope_table": [P, P, I, I, P],
     "mgen_qknorm_rope_fwd": [P, L, P, P, L, L, P, P, P, P, I, L, I, I, I, F, I, P],
     "mgen_qknorm_rope_bwd": [P, L, P, P, L, L, P, L, P, P, P, P, P, P, I, L, I, I, I, F, I, P],
+    "mgen_qknorm_rope_il_fwd": [P, L, P, P, L, L, P, P, P, P, I, L, I, I, I, F, I, P],
+    "mgen_qknorm_rope_il_bwd": [P, L, P, P, L, L, P, L, P, P, P, P, P, P, I, L, I, I, I, F, I, P],
     "mgen_rope4d_table": [P, P, P, L, I, P],
     "mgen_qkvnorm_rope4d_fwd": [P, L, P, P, P, L, L, L, P, P, P, L, I, I, I, I, F, I, P],
     "mgen_qkvnorm_rope4d_bwd": [P, L, P, P, P, L, L, L, P, L, P, P, P, P, P, L, I, I, I, I, F, I, P],

@@ -21,6 +21,7 @@ class LMConfig:
     rope_theta: float = 1e6
     tie_word_embeddings: bool = True
     qk_norm: bool = True           # Qwen3 blocks normalise q and k per head; Llama blocks do not
+    rope_interleaved: bool = False  # rotation pairs (2i, 2i+1) instead of (i, i + head_dim/2) (token models)
     bos_token_id: int = 1
     eos_token_id: int = 2
     pad_token_id: int = 0

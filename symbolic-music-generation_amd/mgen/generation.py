@@ -91,7 +91,8 @@ class GenerationMixin:
         for l, v in enumerate(self._layers):
             ops.linear_fwd(buf.x, v.s_qkv, buf.qkv)
             qp = buf.qk.data_ptr()
-            ops.qknorm_rope_fwd(buf.qkv, NQ, qp, qp + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, 1, B, H, KVH, Dh, eps)
+            ops.qknorm_rope_fwd(buf.qkv, NQ, qp, qp + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, 1, B, H, KVH, Dh, eps,
+                                interleaved=cfg.rope_interleaved)
             ops.kv_append(qp + 2 * H * Dh, buf.qkv.data_ptr() + 2 * QK, QK, NQ, cache.k[l], cache.v[l], pos, B, 1, KVH,
                           Dh, cache.max_len)
             ops.attn_decode(qp, QK, cache.k[l], cache.v[l], kv_len, buf.att, H * Dh, ws, B, H, KVH, Dh, cache.max_len,

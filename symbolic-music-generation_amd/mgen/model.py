@@ -585,7 +585,7 @@ class MidiLM(GenerationMixin, nn.Module):
                 qp, kp, vp = qk.data_ptr(), qk.data_ptr() + esz * H * Dh, qkv.data_ptr() + esz * QK
                 sq, sk, sv = LK, LK, LQ
                 ops.qknorm_rope_fwd(qkv, LQ, qp, kp, LK, LK, v.w_qn, v.w_kn, cs, pos, S, T, H, KVH, Dh,
-                                    cfg.rms_norm_eps)
+                                    cfg.rms_norm_eps, interleaved=cfg.rope_interleaved)
             if cache is not None:  # prefill: rotated keys and values of every prompt position go into the cache
                 ops.kv_append(kp, vp, sk, sv, cache.k[l], cache.v[l], cache.zero_pos, B, S, KVH, Dh, cache.max_len)
             apad = _ATT_PAD if (qpad and (H * Dh * esz) % 2048 == 0) else 0
@@ -780,7 +780,7 @@ class MidiLM(GenerationMixin, nn.Module):
                                        cs, T, H, KVH, KVH, Dh, cfg.rms_norm_eps, is_bf16=not f32)
             else:
                 ops.qknorm_rope_bwd(dqp, LDQ, dqp, dkp, LDQ, LDQ, qkv, qkv.stride(0), v.w_qn, v.w_kn, v.g_qn, v.g_kn, cs, None, S,
-                                    T, H, KVH, Dh, cfg.rms_norm_eps, is_bf16=not f32)
+                                    T, H, KVH, Dh, cfg.rms_norm_eps, is_bf16=not f32, interleaved=cfg.rope_interleaved)
             if fused:
                 lo.bwd_fused(dqkv, x1, lts[0], v.s_qkv, la, "qkv", dx, d, NQ)
             else:

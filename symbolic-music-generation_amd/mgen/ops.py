@@ -252,14 +252,15 @@ def rope_table(inv_freq, npos):
     return cs
 
 
-def qknorm_rope_fwd(qkv, ld_in, qout, kout, ld_q, ld_k, wq, wk, cs, pos, S, T, HQ, HK, D, eps):
-    call("mgen_qknorm_rope_fwd", _p(qkv), ld_in, qout, kout, ld_q, ld_k, _p(wq), _p(wk), _p(cs), _p(pos), S, T, HQ,
+def qknorm_rope_fwd(qkv, ld_in, qout, kout, ld_q, ld_k, wq, wk, cs, pos, S, T, HQ, HK, D, eps, interleaved=False):
+    """interleaved: adjacent rotation pairs (2i, 2i+1) instead of the split-half pairs (i, i + D/2)."""
+    call("mgen_qknorm_rope_il_fwd" if interleaved else "mgen_qknorm_rope_fwd", _p(qkv), ld_in, qout, kout, ld_q, ld_k, _p(wq), _p(wk), _p(cs), _p(pos), S, T, HQ,
          HK, D, eps, int(qkv.dtype == torch.bfloat16), _stream())
 
 
 def qknorm_rope_bwd(dqk, ld_in, dq_raw, dk_raw, ld_q, ld_k, raw, ld_raw, wq, wk, dwq, dwk, cs, pos, S, T, HQ, HK, D,
-                    eps, is_bf16=True):
-    call("mgen_qknorm_rope_bwd", dqk, ld_in, dq_raw, dk_raw, ld_q, ld_k, _p(raw), ld_raw, _p(wq), _p(wk), _p(dwq),
+                    eps, is_bf16=True, interleaved=False):
+    call("mgen_qknorm_rope_il_bwd" if interleaved else "mgen_qknorm_rope_bwd", dqk, ld_in, dq_raw, dk_raw, ld_q, ld_k, _p(raw), ld_raw, _p(wq), _p(wk), _p(dwq),
          _p(dwk), _p(cs), _p(pos), S, T, HQ, HK, D, eps, int(is_bf16), _stream())
 
 

@@ -76,3 +76,36 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def pair_perm(Dh):
+    """Row order that turns a split-half head into the adjacent-pair head with the same rotation pairs:
+    new[2i] = old[i], new[2i + 1] = old[i + Dh/2]."""
+    idx = torch.empty(Dh, dtype=torch.long)
+    idx[0::2] = torch.arange(Dh // 2)
+    idx[1::2] = torch.arange(Dh // 2) + Dh // 2
+    return idx
+
+
+def to_interleaved(params, cfg):
+    """The adjacent-pair (rope_interleaved) twin of a split-half model: q/k projection rows and q/k norm gains
+    permuted within each head; every other tensor unchanged. Both models compute the same function."""
+    idx = pair_perm(cfg.head_dim)
+    out = dict(params)
+    for k, v in params.items():
+        if k.endswith("q_proj.weight") or k.endswith("k_proj.weight"):
+            H = v.shape[0] // cfg.head_dim
+            out[k] = v.view(H, cfg.head_dim, -1)[:, idx, :].reshape(v.shape).contiguous()
+        elif k.endswith("q_norm.weight") or k.endswith("k_norm.weight"):
+            out[k] = v[idx].contiguous()
+    return out
+
+
+def rows_from_interleaved(t, cfg):
+    """Inverse of the row permutation of to_interleaved for a q/k projection weight (or its gradient)."""
+    t = torch.as_tensor(t)
+    inv = torch.argsort(pair_perm(cfg.head_dim))
+    if t.dim() == 1:
+        return t[inv]
+    H = t.shape[0] // cfg.head_dim
+    return t.view(H, cfg.head_dim, -1)[:, inv, :].reshape(t.shape)

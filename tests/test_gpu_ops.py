@@ -175,8 +175,11 @@ def test_rmsnorm_fwd_bwd(ops, T, d):
 
 
 # ----------------------------------------------------------------------------------------------- rope
+# il: adjacent rotation pairs (2i, 2i+1) instead of the split-half pairs
+@pytest.mark.parametrize("il", [False, True])
 @pytest.mark.parametrize("D,norm", [(128, True), (64, False), (128, False), (64, True)])
-def test_qknorm_rope_fwd_bwd(ops, D, norm):
+def test_qknorm_rope_fwd_bwd(ops, D, norm, il):
+    rope = R.apply_rope_interleaved if il else R.apply_rope
     B, S, HQ, HK = 2, 37, 3, 2
     T = B * S
     g = torch.Generator().manual_seed(D + norm)
@@ -194,8 +197,8 @@ def test_qknorm_rope_fwd_bwd(ops, D, norm):
         if norm:
             q = R.rmsnorm(bf(q), wq_, 1e-6)
             k = R.rmsnorm(bf(k), wk_, 1e-6)
-        q = R.apply_rope(q.transpose(1, 2).float(), cos, sin).transpose(1, 2)
-        k = R.apply_rope(k.transpose(1, 2).float(), cos, sin).transpose(1, 2)
+        q = rope(q.transpose(1, 2).float(), cos, sin).transpose(1, 2)
+        k = rope(k.transpose(1, 2).float(), cos, sin).transpose(1, 2)
         return q.reshape(T, HQ * D), k.reshape(T, HK * D)
 
     q_ref, k_ref = ref(qkv.float(), wq, wk)
@@ -207,14 +210,14 @@ def test_qknorm_rope_fwd_bwd(ops, D, norm):
     qd = qkv.to(dev())
     wqd, wkd = (wq.to(dev()), wk.to(dev())) if norm else (None, None)
     ops.qknorm_rope_fwd(qd, NQ, out.data_ptr(), out.data_ptr() + 2 * HQ * D, QK, QK, wqd, wkd, cs, None, S, T, HQ,
-                        HK, D, 1e-6)
+                        HK, D, 1e-6, interleaved=il)
     assert rel(out[:, :HQ * D].float(), q_ref) < 1e-2
     assert rel(out[:, HQ * D:].float(), k_ref) < 1e-2
     # explicit positions give the same result
     posd = pos.reshape(-1).to(torch.int32).to(dev())
     out2 = torch.empty_like(out)
     ops.qknorm_rope_fwd(qd, NQ, out2.data_ptr(), out2.data_ptr() + 2 * HQ * D, QK, QK, wqd, wkd, cs, posd, S, T, HQ,
-                        HK, D, 1e-6)
+                        HK, D, 1e-6, interleaved=il)
     assert torch.equal(out, out2)
 
     # backward against autograd of the fp32 formula (rounding of the normalised value treated as identity)
@@ -226,8 +229,8 @@ def test_qknorm_rope_fwd_bwd(ops, D, norm):
     if norm:
         q = R.rmsnorm(q, wq_r, 1e-6)
         k = R.rmsnorm(k, wk_r, 1e-6)
-    q = R.apply_rope(q.transpose(1, 2), cos, sin).transpose(1, 2).reshape(T, HQ * D)
-    k = R.apply_rope(k.transpose(1, 2), cos, sin).transpose(1, 2).reshape(T, HK * D)
+    q = rope(q.transpose(1, 2), cos, sin).transpose(1, 2).reshape(T, HQ * D)
+    k = rope(k.transpose(1, 2), cos, sin).transpose(1, 2).reshape(T, HK * D)
     dqk = bf(torch.randn(T, NQ, generator=g))
     (q * dqk[:, :HQ * D].float()).sum().backward(retain_graph=True)
     (k * dqk[:, HQ * D:QK].float()).sum().backward()
@@ -236,7 +239,7 @@ def test_qknorm_rope_fwd_bwd(ops, D, norm):
     dwk = torch.zeros(D, dtype=torch.float32, device=dev())
     p = buf.data_ptr()
     ops.qknorm_rope_bwd(p, NQ, p, p + 2 * HQ * D, NQ, NQ, qd, NQ, wqd, wkd, dwq if norm else None,
-                        dwk if norm else None, cs, None, S, T, HQ, HK, D, 1e-6)
+                        dwk if norm else None, cs, None, S, T, HQ, HK, D, 1e-6, interleaved=il)
     assert rel(buf[:, :QK].float(), xf.grad[:, :QK]) < 1.5e-2
     assert torch.equal(buf[:, QK:].cpu(), dqk[:, QK:]), "v section must be untouched"
     if norm:
