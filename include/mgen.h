@@ -66,7 +66,9 @@ int mgen_slab_resid_rmsnorm(const float* slabs, int nslabs, long slab_stride, co
 int mgen_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, long T, int d, float eps, int out_bf16,
                      mgen_stream_t stream);
 /* autograd backward of the above: dres (fp32 [T,d]) = (accumulate ? dres : 0) + dx; optional copy of the updated dres
- * in the dy dtype (dres_lp, may be null); dw[d] += sum_rows dy * x * rstd (atomic adds). */
+ * in the dy dtype (dres_lp, may be null); dw[d] += sum_rows dy * x * rstd. The blocks of a launch meet in a small
+ * device array that the library owns (one per GPU): calls on one stream are ordered, calls that overlap on one GPU
+ * from different streams would race on it. */
 int mgen_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dres, void* dres_lp,
                      float* dw, long T, int d, int accumulate, int dy_bf16, mgen_stream_t stream);
 

@@ -74,9 +74,15 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     }
 }
 
-// Workgroups of 16 waves: the gain gradient costs one atomic per element per WORKGROUP, and thousands of atomics
-// on the same d addresses serialise in L2, so few large workgroups carry the same number of waves as many small ones.
-// (16 waves for rows of up to 512 elements; 4 for longer rows, whose per-lane state needs more than 128 VGPRs.)
+// Copies of the gain-gradient row that the blocks of one mgen_rmsnorm_bwd launch add into, and the ticket counter of
+// that launch; all zero between launches. One array per device, shared by every call on it: calls that overlap on one
+// GPU (different streams) race on it; calls on one stream are ordered.
+constexpr int NORM_DW_COPIES = 8;
+static __device__ float g_dw_copies[NORM_DW_COPIES * 2048];
+static __device__ unsigned g_dw_ticket;
+
+// Workgroups of 16 waves, one per CU (16 waves for rows of up to 512 elements; 4 for longer rows, whose per-lane
+// state needs more than 128 VGPRs).
 template <int VPL, typename DyT, int BWD_WAVES = (VPL <= 2 ? 16 : 4)>
 __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* __restrict__ dy,
                                                                      const float* __restrict__ x,
@@ -133,7 +139,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* 
             }
         }
     }
-    // dw: sum the 4 waves of the block through LDS, then one atomic per element per block
+    // dw: the waves of the block meet in LDS; the blocks meet in NORM_DW_COPIES copies of the gain-gradient row kept
+    // in a device array (block b adds into copy b % NORM_DW_COPIES with atomics), and the block that draws the last
+    // ticket adds the copies to dw and clears them. (One atomic per element and block straight into dw serialises
+    // 256-512 adds on each of the same d addresses: 17 us of a 98 us launch at 256 blocks, 31 us at 512.)
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         __syncthreads();
@@ -143,9 +152,34 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* 
             f32x4 s = *reinterpret_cast<f32x4*>(&red[lane * 4]);
             for (int k = 1; k < BWD_WAVES; ++k) s += *reinterpret_cast<f32x4*>(&red[(k * 64 + lane) * 4]);
             const int c = (i * 64 + lane) * 4;
+            float* copy = g_dw_copies + (blockIdx.x % NORM_DW_COPIES) * 2048;
             if (c < d)
-                for (int e = 0; e < 4; ++e) atomicAdd(dw + c + e, s[e]);
+                for (int e = 0; e < 4; ++e) atomicAdd(copy + c + e, s[e]);
         }
+    }
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();   // this block's adds are performed before its ticket
+        is_last = atomicAdd(&g_dw_ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+        __threadfence();
+        for (int col = threadIdx.x; col < d; col += blockDim.x) {
+            float v[NORM_DW_COPIES];
+#pragma unroll
+            for (int r = 0; r < NORM_DW_COPIES; ++r)
+                v[r] = __hip_atomic_load(&g_dw_copies[r * 2048 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < NORM_DW_COPIES; ++r) {
+                acc += v[r];
+                g_dw_copies[r * 2048 + col] = 0.f;   // clean for the next launch
+            }
+            dw[col] += acc;
+        }
+        if (threadIdx.x == 0) g_dw_ticket = 0u;   // launches of one stream are ordered
     }
 }
 
@@ -182,7 +216,8 @@ extern "C" int mgen_rmsnorm_bwd(const void* dy, const float* x, const float* w, 
     DISPATCH_VPL(d, {
         constexpr int NW = VPL <= 2 ? 16 : 4;
         const long b = (T + NW - 1) / NW;
-        const dim3 grid((int)(b < 512 ? b : 512));
+        const long cap = VPL <= 2 ? 256 : 512;   // one 16-wave block per CU / two 4-wave blocks
+        const dim3 grid((int)(b < cap ? b : cap));
         const dim3 block(64 * NW);
         if (dy_bf16)
             hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, bf16>), grid, block, 0, stream, (const bf16*)dy, x, w, rstd,
