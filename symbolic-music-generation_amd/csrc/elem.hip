@@ -8,7 +8,9 @@
 
 namespace {
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// (v_rcp_f32, 1 ulp: a correctly rounded fp32 division costs ten instructions per element, which the GEMM epilogue
+// that shares this formula pays beside its MFMAs; the result is rounded to bf16 anyway)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // gu: [T, 2I] = [gate | up] per row; act: [T, I]
 template <bool BF16ROUND>

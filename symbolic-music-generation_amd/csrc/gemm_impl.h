@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256 * WM, WM == 2 ? 2 : (GLDS ? (NJ == 4 ? 2 : 3) :
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float gf = (float)gv[e];
-                    const float sl = round_bf(gf * (1.f / (1.f + __expf(-gf))));
+                    const float sl = round_bf(gf * __builtin_amdgcn_rcpf(1.f + __expf(-gf)));   // as sigmoidf_ in elem.hip
                     o[e] = (bf16)(sl * (float)uv[e]);
                 }
                 const int m = m0 + wm + row;

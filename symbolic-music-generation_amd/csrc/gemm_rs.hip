@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rs_kernel(RsArgs g) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gf = (float)gv[e];
-            const float sl = round_bf(gf * (1.f / (1.f + __expf(-gf))));
+            const float sl = round_bf(gf * __builtin_amdgcn_rcpf(1.f + __expf(-gf)));   // as sigmoidf_ in elem.hip
             o[e] = (bf16)(sl * (float)uv[e]);
         }
         bf16* c = g.C + (long)(mrow0 + row) * g.ldc + 32 * gp + ch * 8;
