@@ -259,7 +259,7 @@ extern "C" int mgen_layernorm_bwd(const void* dy, const float* x, const float* w
                                   int accumulate, int dy_bf16, hipStream_t stream) {
     MGEN_REQUIRE(dy && x && w && mean && rstd && dres && dw && db, "mgen_layernorm_bwd: null pointer");
     MGEN_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && d <= 2048, "mgen_layernorm_bwd: need 0<d<=2048, d%%4==0 (d=%d)", d);
-    const dim3 grid(ln_grid(T, 1024)), block(256);
+    const dim3 grid(ln_grid(T, 512)), block(256);
     DISPATCH_VPL(d, {
         if (dy_bf16)
             hipLaunchKernelGGL((layernorm_bwd_kernel<VPL, bf16>), grid, block, 0, stream, (const bf16*)dy, x, w, mean,
