@@ -228,3 +228,33 @@ def test_grouped_weight_gradients(ops):
     ops.linear_wgrad_group(small)
     ref = small[0][0].float().t() @ small[0][1].float()
     assert float((small[0][2] - ref).abs().max()) / float(ref.abs().max()) < 2e-5
+
+
+def test_row_padding_changes_nothing(ops):
+    """The 128 bytes of row padding that the training step gives qkv, the rotated q|k, the attention output and the
+    gradient activations (pitches that would be multiples of 2 KiB) must not change a bit of the loss; gradients agree
+    up to the summation order of the weight-gradient atomics."""
+    from mgen import MidiLM
+    import mgen.model as mm
+    from mgen.config import default_decoder
+    cfg = default_decoder()
+    cfg.num_hidden_layers = 2
+    cfg.lm_head_chunk_tokens = 16384
+    model = MidiLM(cfg, device="cuda:0", seed=2)
+    g = torch.Generator().manual_seed(10)
+    ids = torch.randint(3, cfg.vocab_size, (8, 2048), generator=g).to(dev())
+    saved = (mm._ROW_PAD, mm._ATT_PAD)
+    outs = []
+    try:
+        for pad in (64, 0):
+            mm._ROW_PAD = mm._ATT_PAD = pad
+            model.zero_grad()
+            loss = model(input_ids=ids, labels=ids).loss
+            loss.backward()
+            outs.append((loss.detach().clone(), model.flat_grad.clone()))
+    finally:
+        mm._ROW_PAD, mm._ATT_PAD = saved
+    (l1, g1), (l0, g0) = outs
+    assert torch.equal(l1, l0), (float(l1), float(l0))
+    err = float((g1 - g0).abs().max() / g0.abs().max())
+    assert err < 1e-5, err
