@@ -116,6 +116,37 @@ def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
             "sampling": "T=0.97 top_p=0.95 top_k=off philox(seed 1234)", "out_shape": list(out.shape)}
 
 
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process (which has not touched
+    the GPU) starts N fresh rank processes through torch.distributed.run with the same arguments, relays their
+    output (rank 0 prints the one JSON line) and exits with their return code. Under a launcher (WORLD_SIZE set) the
+    flag must agree with it. Never returns in the parent case."""
+    import socket
+    import subprocess
+    rehearse = os.environ.get("MGEN_REHEARSE_ON_ONE_GPU") == "1"
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    have = torch.cuda.device_count()     # counts devices without creating a GPU context
+    if args.gpus > have and not rehearse:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible "
+                         "(MGEN_REHEARSE_ON_ONE_GPU=1 puts every rank on device 0 for a control-flow rehearsal)")
+    if args.gpus == 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between processes here
+    env.setdefault("OMP_NUM_THREADS", "4")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--decode-streams", type=int, default=256)
@@ -136,6 +167,7 @@ def main():
                          "dropout of 0.1 (--pdrop); decode and CPU legs are skipped for both")
     ap.add_argument("--pdrop", type=float, default=0.1, help="dropout probability of --model gpt2")
     args = ap.parse_args()
+    launch_ranks_if_needed(args)
 
     from mgen import MidiLM, default_decoder, aria_style_llama, ops
     from mgen.config import gpt2_decoder
@@ -193,50 +225,64 @@ def main():
     # bf16 output (QKV, lm_head logits, o_proj / down_proj input gradients through the transposed weight copies).
     # One extra step with a HIP event pair around every launch of that kernel on its stream.
     roofline = None
-    if True:  # every rank runs the extra step (it contains collectives for N > 1); rank 0 reports
-        recs = []
-        orig = ops.gemm
+    # every rank runs the extra step (it contains collectives for N > 1); rank 0 reports
+    recs = []
+    orig = ops.gemm
 
-        def timed_gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode=ops.OUT_BF16, *rest,
-                       **kw):
-            if not trans_a and not trans_b and out_mode == ops.OUT_BF16:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                orig(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, *rest, **kw)
-                e1.record()
-                recs.append((2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N)))
-            else:
-                orig(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, *rest, **kw)
+    def timed_gemm(a, b, c, M, N, K, lda, ldb, ldc, trans_a=False, trans_b=False, out_mode=ops.OUT_BF16, *rest,
+                   **kw):
+        if not trans_a and not trans_b and out_mode == ops.OUT_BF16:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, *rest, **kw)
+            e1.record()
+            recs.append((2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N)))
+        else:
+            orig(a, b, c, M, N, K, lda, ldb, ldc, trans_a, trans_b, out_mode, *rest, **kw)
 
-        ops.gemm = timed_gemm
-        trainer.training_step(batch)
-        torch.cuda.synchronize()
-        ops.gemm = orig
-        fl = sum(r[0] for r in recs)
-        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
-        achieved = fl / (ms * 1e-3) / 1e12
-        # HBM traffic per launch of this kernel cannot be counted from inside the process: it comes from the committed
-        # PMC passes of this same command (profiles/r02_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs,
-        # FETCH doubled per the gfx950 note), valid for the default workload only
-        traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-        if (B, S) == (32, 2048) and args.model == "default" and os.path.exists(pmc):
-            with open(pmc) as fh:
-                traffic = json.load(fh).get("roofline_kernel_avg_bytes_per_launch")
-        # (the other --model choices have no 512-long reductions: their x @ W^T products run on the tile-loop kernel)
-        kname = ("gemm_rs_kernel<false, 0> (bf16 products with a 512-long reduction: QKV, lm_head logits, "
-                 "o_proj / down_proj input gradients)") if cfg.hidden_size == 512 and args.model == "default" else \
-            "x @ W^T products with a bf16 output (all shapes of this model; kernel chosen per shape)"
-        roofline = {"bound": "mfma", "kernel": kname,
-                    "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r02_pmc_traffic.json); algorithmic: "
-                                    "2*(M*K + N*K + M*N) bytes",
-                    "algorithmic_bytes_per_launch": round(sum(r[3] for r in recs) / len(recs)),
-                    "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 4),
-                    "flops_per_launch_avg": fl / len(recs)}
+    ops.gemm = timed_gemm
+    trainer.training_step(batch)
+    torch.cuda.synchronize()
+    ops.gemm = orig
+    fl = sum(r[0] for r in recs)
+    ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+    achieved = fl / (ms * 1e-3) / 1e12
+    # HBM traffic per launch of this kernel cannot be counted from inside the process: it comes from the committed
+    # PMC passes of this same command (profiles/r02_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs,
+    # FETCH doubled per the gfx950 note), valid for the default workload only
+    traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    if (B, S) == (32, 2048) and args.model == "default" and os.path.exists(pmc):
+        with open(pmc) as fh:
+            traffic = json.load(fh).get("roofline_kernel_avg_bytes_per_launch")
+    # (the other --model choices have no 512-long reductions: their x @ W^T products run on the tile-loop kernel)
+    kname = ("gemm_rs_kernel<false, 0> (bf16 products with a 512-long reduction: QKV, lm_head logits, "
+             "o_proj / down_proj input gradients)") if cfg.hidden_size == 512 and args.model == "default" else \
+        "x @ W^T products with a bf16 output (all shapes of this model; kernel chosen per shape)"
+    roofline = {"bound": "mfma", "kernel": kname,
+                "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC, profiles/r02_pmc_traffic.json); algorithmic: "
+                                "2*(M*K + N*K + M*N) bytes",
+                "algorithmic_bytes_per_launch": round(sum(r[3] for r in recs) / len(recs)),
+                "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 4),
+                "flops_per_launch_avg": fl / len(recs)}
 
+    ranks_seen = 1
     if world > 1:
+        # every rank contributes a 1 through the same collective path the gradients use: the sum is the number of
+        # ranks the communicator really joined
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        if trainer.reducer._comm is not None:
+            trainer.reducer._comm.allreduce_(one, average=False)
+            trainer.reducer._comm.wait()
+        elif dist.get_backend() == "nccl":
+            dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        else:
+            host = one.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            one = host
+        ranks_seen = int(round(float(one)))
         dist.barrier()
     if rank == 0:
         ftok = train_flops_per_token(cfg, S)
@@ -255,6 +301,7 @@ def main():
         if world > 1:
             log = list(trainer.reducer.bucket_log)
             out["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                           "ranks_seen": ranks_seen,
                            "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())
                            if dist.get_backend() == "nccl" else None,
                            "collective": "all_reduce(AVG)" if trainer.reducer._native_avg else "all_reduce(SUM) / N",

@@ -10,6 +10,9 @@
 // dx is added into the fp32 gradient of the residual stream (the norm sits on a residual branch) and the updated
 // gradient is also emitted in the GEMM input dtype for the next dgrad/wgrad.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -75,22 +78,25 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 }
 
 // Copies of the gain-gradient row that the blocks of one mgen_rmsnorm_bwd launch add into, and the ticket counter of
-// that launch; all zero between launches. One array per device, shared by every call on it: calls that overlap on one
-// GPU (different streams) race on it; calls on one stream are ordered.
+// that launch; all zero between launches. The device array holds NORM_DW_SLOTS such sets: the entry point gives every
+// (device, stream) pair a set of its own, so launches that overlap on one GPU (different streams) never share one, and
+// launches on one stream are ordered. A stream that finds every set taken runs the DIRECT form (atomics straight into
+// dw: no shared state at all).
 constexpr int NORM_DW_COPIES = 8;
-static __device__ float g_dw_copies[NORM_DW_COPIES * 2048];
-static __device__ unsigned g_dw_ticket;
+constexpr int NORM_DW_SLOTS = 16;
+static __device__ float g_dw_copies[NORM_DW_SLOTS * NORM_DW_COPIES * 2048];
+static __device__ unsigned g_dw_ticket[NORM_DW_SLOTS];
 
 // Workgroups of 16 waves, one per CU (16 waves for rows of up to 512 elements; 4 for longer rows, whose per-lane
 // state needs more than 128 VGPRs).
-template <int VPL, typename DyT, int BWD_WAVES = (VPL <= 2 ? 16 : 4)>
+template <int VPL, typename DyT, bool DIRECT, int BWD_WAVES = (VPL <= 2 ? 16 : 4)>
 __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* __restrict__ dy,
                                                                      const float* __restrict__ x,
                                                                      const float* __restrict__ w,
                                                                      const float* __restrict__ rstd,
                                                                      float* __restrict__ dres,
                                                                      DyT* __restrict__ dres_lp, float* __restrict__ dw,
-                                                                     long T, int d, int accumulate) {
+                                                                     long T, int d, int accumulate, int slot) {
     __shared__ float red[BWD_WAVES * 64 * 4];  // per-wave dw partials for one 256-element slab of the row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wave0 = (long)blockIdx.x * BWD_WAVES + wave;
@@ -152,35 +158,70 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* 
             f32x4 s = *reinterpret_cast<f32x4*>(&red[lane * 4]);
             for (int k = 1; k < BWD_WAVES; ++k) s += *reinterpret_cast<f32x4*>(&red[(k * 64 + lane) * 4]);
             const int c = (i * 64 + lane) * 4;
-            float* copy = g_dw_copies + (blockIdx.x % NORM_DW_COPIES) * 2048;
+            float* copy = DIRECT ? dw : g_dw_copies + ((long)slot * NORM_DW_COPIES + blockIdx.x % NORM_DW_COPIES) * 2048;
             if (c < d)
                 for (int e = 0; e < 4; ++e) atomicAdd(copy + c + e, s[e]);
+            if (!DIRECT) __threadfence();   // every lane that added: its adds are performed before the block's ticket
         }
     }
+    if (DIRECT) return;
     __shared__ int is_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();   // this block's adds are performed before its ticket
-        is_last = atomicAdd(&g_dw_ticket, 1u) == gridDim.x - 1;
+        __threadfence();
+        is_last = atomicAdd(&g_dw_ticket[slot], 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (is_last) {
         __threadfence();
+        float* copies = g_dw_copies + (long)slot * NORM_DW_COPIES * 2048;
         for (int col = threadIdx.x; col < d; col += blockDim.x) {
             float v[NORM_DW_COPIES];
 #pragma unroll
             for (int r = 0; r < NORM_DW_COPIES; ++r)
-                v[r] = __hip_atomic_load(&g_dw_copies[r * 2048 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[r] = __hip_atomic_load(&copies[r * 2048 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float acc = 0.f;
 #pragma unroll
             for (int r = 0; r < NORM_DW_COPIES; ++r) {
                 acc += v[r];
-                g_dw_copies[r * 2048 + col] = 0.f;   // clean for the next launch
+                copies[r * 2048 + col] = 0.f;   // clean for the next launch
             }
             dw[col] += acc;
         }
-        if (threadIdx.x == 0) g_dw_ticket = 0u;   // launches of one stream are ordered
+        if (threadIdx.x == 0) g_dw_ticket[slot] = 0u;   // launches of one stream are ordered
     }
+}
+
+// (device, stream) -> set of gain-gradient copies; -1 when all sets of the device are taken by other streams
+int norm_dw_slot(hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int> slots;
+    static std::map<int, int> used;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = slots.find({dev, stream});
+    if (it != slots.end()) return it->second;
+    int& n = used[dev];
+    if (n >= NORM_DW_SLOTS) return -1;
+    slots[{dev, stream}] = n;
+    return n++;
+}
+
+template <int VPL, typename DyT>
+void launch_rmsnorm_bwd(hipStream_t stream, int slot, const void* dy, const float* x, const float* w,
+                        const float* rstd, float* dres, void* dres_lp, float* dw, long T, int d, int accumulate) {
+    constexpr int NW = VPL <= 2 ? 16 : 4;
+    const long b = (T + NW - 1) / NW;
+    const long cap = VPL <= 2 ? 256 : 512;   // one 16-wave block per CU / two 4-wave blocks
+    const dim3 grid((int)(b < cap ? b : cap));
+    const dim3 block(64 * NW);
+    if (slot >= 0)
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, DyT, false>), grid, block, 0, stream, (const DyT*)dy, x, w, rstd,
+                           dres, (DyT*)dres_lp, dw, T, d, accumulate, slot);
+    else
+        hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, DyT, true>), grid, block, 0, stream, (const DyT*)dy, x, w, rstd,
+                           dres, (DyT*)dres_lp, dw, T, d, accumulate, 0);
 }
 
 inline int norm_grid(long T) {
@@ -213,18 +254,13 @@ extern "C" int mgen_rmsnorm_bwd(const void* dy, const float* x, const float* w, 
                                 hipStream_t stream) {
     MGEN_REQUIRE(dy && x && w && rstd && dres && dw, "mgen_rmsnorm_bwd: null pointer");
     MGEN_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && d <= 2048, "mgen_rmsnorm_bwd: need 0<d<=2048, d%%4==0 (d=%d)", d);
-    DISPATCH_VPL(d, {
-        constexpr int NW = VPL <= 2 ? 16 : 4;
-        const long b = (T + NW - 1) / NW;
-        const long cap = VPL <= 2 ? 256 : 512;   // one 16-wave block per CU / two 4-wave blocks
-        const dim3 grid((int)(b < cap ? b : cap));
-        const dim3 block(64 * NW);
-        if (dy_bf16)
-            hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, bf16>), grid, block, 0, stream, (const bf16*)dy, x, w, rstd,
-                               dres, (bf16*)dres_lp, dw, T, d, accumulate);
-        else
-            hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, float>), grid, block, 0, stream, (const float*)dy, x, w, rstd,
-                               dres, (float*)dres_lp, dw, T, d, accumulate);
-    });
+    const int slot = norm_dw_slot(stream);
+    if (d <= 512) {
+        if (dy_bf16) launch_rmsnorm_bwd<2, bf16>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
+        else launch_rmsnorm_bwd<2, float>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
+    } else {
+        if (dy_bf16) launch_rmsnorm_bwd<8, bf16>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
+        else launch_rmsnorm_bwd<8, float>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
+    }
     return mgen_check_launch("mgen_rmsnorm_bwd");
 }

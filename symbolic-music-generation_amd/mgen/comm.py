@@ -35,7 +35,8 @@ class NativeComm:
                 call("mgen_comm_unique_id", buf)
             box = [buf.raw]
             if world > 1:
-                dist.broadcast_object_list(box, src=0, group=group)
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=group)
             unique_id = box[0]
         assert len(unique_id) == 128
         self.rank, self.world, self.device = rank, world, device

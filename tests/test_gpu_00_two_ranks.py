@@ -1,5 +1,5 @@
-"""bench.py launched the way the multi-GPU measurement launches it (torch.distributed.run, one process per rank), with
-two ranks sharing the one GPU of the test machine: MGEN_REHEARSE_ON_ONE_GPU=1 puts both on device 0 and routes the
+"""bench.py launched both ways the multi-GPU measurement may launch it - plain `python bench.py --gpus 2` (the script
+starts its own ranks) and under torch.distributed.run (one process per rank) - with two ranks sharing the one GPU of the test machine: MGEN_REHEARSE_ON_ONE_GPU=1 puts both on device 0 and routes the
 gradient exchange through gloo (RCCL refuses two ranks on one device). Checks the control flow of the N > 1 path -
 gradient hooks and buckets, barriers, the max-over-ranks time, one JSON line from rank 0 - not its speed.
 
@@ -18,14 +18,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_bench_prints_one_json_line():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_two_rank_bench_prints_one_json_line(launcher):
     env = dict(os.environ, MGEN_REHEARSE_ON_ONE_GPU="1", MGEN_BENCH_WATCHDOG="150")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--batch", "2", "--seq", "512", "--no-cpu-baseline"]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--seq",
+            "512", "--no-cpu-baseline"]
+    if launcher == "plain":
+        cmd = [sys.executable] + tail
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -34,6 +41,7 @@ def test_two_rank_bench_prints_one_json_line():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and abs(out["value"] - 2 * 2 * 512 * 2 / (out["ms_per_step"] * 2e-3)) < 0.01 * out["value"]
+    assert out["comm"]["world_size"] == 2 and out["comm"]["ranks_seen"] == 2
     assert out["roofline"]["achieved"] > 0
     assert 0 < out["final_loss"] < 13.0
 

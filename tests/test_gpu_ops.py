@@ -174,6 +174,30 @@ def test_rmsnorm_fwd_bwd(ops, T, d):
     assert rel(dres, xr.grad) < 1e-5
 
 
+def test_rmsnorm_bwd_overlapping_streams(ops):
+    """Launches that overlap on one GPU (one per stream, several rounds) keep their gain gradients apart: each
+    (device, stream) owns a set of partial-sum rows; more streams than sets fall back to plain atomics."""
+    T, d, NS = 20000, 512, 20
+    g = torch.Generator().manual_seed(5)
+    streams = [torch.cuda.Stream() for _ in range(NS)]
+    cases = []
+    for i in range(NS):
+        x = (torch.randn(T, d, generator=g) * (1 + i)).to(dev())
+        dy = bf(torch.randn(T, d, generator=g)).to(dev())
+        w = (1 + 0.1 * torch.randn(d, generator=g)).to(dev())
+        rstd = torch.rsqrt((x * x).mean(-1) + 1e-6)
+        want = (dy.float() * x * rstd[:, None]).sum(0)
+        cases.append((x, dy, w, rstd, want, torch.zeros(d, device=dev()), torch.empty(T, d, device=dev())))
+    torch.cuda.synchronize()
+    for rnd in range(3):
+        for st, (x, dy, w, rstd, want, dw, dres) in zip(streams, cases):
+            with torch.cuda.stream(st):
+                ops.rmsnorm_bwd(dy, x, w, rstd, dres, None, dw, accumulate=False)
+    torch.cuda.synchronize()
+    for x, dy, w, rstd, want, dw, dres in cases:
+        assert rel(dw, 3 * want) < 1e-4
+
+
 # ----------------------------------------------------------------------------------------------- rope
 # il: adjacent rotation pairs (2i, 2i+1) instead of the split-half pairs
 @pytest.mark.parametrize("il", [False, True])
