@@ -331,12 +331,30 @@ int mgen_scale_f32(float* x, long n, float s, const float* a_dev, mgen_stream_t 
 int mgen_axpy_f32(float* y, const float* x, long n, float a, const float* a_dev, mgen_stream_t stream);
 int mgen_scale_bf16(void* x, long n, float a, const float* a_dev, mgen_stream_t stream);
 
+/* Projections of the one-token decode step (few token rows M, small weights): C[M, N] = A[M, K] W[N, K]^T in one
+ * memory round trip per workgroup (64 x 64 x 512 tiles, all operand loads requested up front). slabs == 0: bf16
+ * C [M][ldc], K == 512. slabs != 0: fp32 partial products of the K / 512 reduction slices, slab_stride elements apart
+ * (summed by mgen_slab_resid_rmsnorm). a_swiglu != 0: A is gu [M][lda >= 2K] and the operand is silu(gate) * up
+ * (Qwen3MLP.forward, TF models/qwen3/modeling_qwen3.py:81-83), formed while the tile is loaded.
+ * mgen_gemm_skinny_fits returns 1 for the shapes the kernel takes (N % 64 == 0, K % 512 == 0, M <= 1024, ...).
+ * Replaces the nn.Linear calls of a decoder layer at q_len = 1 (TF models/qwen3/modeling_qwen3.py:252-254, 279). */
+int mgen_gemm_skinny_fits(int M, int N, int K, long lda, long ldw, long ldc, int slabs);
+int mgen_gemm_bf16_skinny(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                          int slabs, long slab_stride, int a_swiglu, mgen_stream_t stream);
+
 /* ---- KV-cache decode ----------------------------------------------------------------------------------------
  * The cache is pre-allocated [B][KVH][max_len][D] bf16 per layer (the reference grows it with torch.cat per token:
  * DynamicLayer.update, TF cache_utils.py:127-146). mgen_kv_append copies n_new tokens per stream from token-major
  * projection outputs (k_src/v_src [B*n_new][ld], heads at h*D) to positions pos0[b] .. pos0[b]+n_new-1. */
 int mgen_kv_append(const void* k_src, const void* v_src, long ld_k, long ld_v, void* k_cache, void* v_cache,
                    const int* pos0, int B, int n_new, int KVH, int D, int max_len, mgen_stream_t stream);
+/* One decode step's projection rows qkv [B][ld_in] (one new token per stream: HQ query heads, HK key heads, HK value
+ * heads) in one launch: q/k per-head RMSNorm (wq/wk, may both be null) + rotation by the table row pos[b]
+ * (TF models/qwen3/modeling_qwen3.py:252-257), q to qout [B][ld_q], k and v into cache slot pos[b] of their stream
+ * (TF cache_utils.py:127-146). Same bits as mgen_qknorm_rope[_il]_fwd followed by mgen_kv_append. */
+int mgen_decode_qkv_prep(const void* qkv, long ld_in, void* qout, long ld_q, void* k_cache, void* v_cache,
+                         const float* wq, const float* wk, const float* cos_sin, const int* pos, int B, int HQ, int HK,
+                         int D, int max_len, float eps, int interleaved, mgen_stream_t stream);
 /* single-query attention over the cache (TF models/qwen3/modeling_qwen3.py:259-279 with q_len = 1): q [B][ld_q],
  * out [B][ld_o] bf16, kv_len[b] keys per stream; nsplit > 1 splits the keys over workgroups and needs
  * mgen_attn_decode_workspace(B, H, D, nsplit) floats of workspace. */
@@ -344,6 +362,14 @@ long mgen_attn_decode_workspace(int B, int H, int D, int nsplit);
 int mgen_attn_decode(const void* q, long ld_q, const void* k_cache, const void* v_cache, const int* kv_len, void* out,
                      long ld_o, float* workspace, int B, int H, int KVH, int D, int max_len, int nsplit, float scale,
                      mgen_stream_t stream);
+
+/* mgen_decode_qkv_prep + mgen_attn_decode in one launch: q, the new key and the new value are taken from the raw
+ * projection rows qkv [B][ld_in] inside the attention kernel (same bits as the two calls). kv_len[b] counts the new
+ * token; the caches are read up to kv_len[b] - 1 keys and receive the new rows at slot pos[b]. */
+int mgen_attn_decode_prep(const void* qkv, long ld_in, const float* wq, const float* wk, const float* cos_sin,
+                          const int* pos, float eps, int interleaved, void* k_cache, void* v_cache, const int* kv_len,
+                          void* out, long ld_o, float* workspace, int B, int H, int KVH, int D, int max_len, int nsplit,
+                          float scale, mgen_stream_t stream);
 
 /* ---- sampler -------------------------------------------------------------------------------------------------
  * GenerationMixin._sample token selection (TF generation/utils.py:2894-2925) with the warpers
@@ -354,6 +380,12 @@ int mgen_attn_decode(const void* q, long ld_q, const void* k_cache, const void* 
 int mgen_sample(const void* logits, long ld, int B, int V, int is_bf16, int do_sample, float temperature, int top_k,
                 float top_p, const float* noise, long ld_noise, unsigned long long seed, unsigned long long offset,
                 long* out, long* out2, long out2_stride, mgen_stream_t stream);
+/* mgen_sample on rows [row0, row0 + B) of a larger batch: the Philox stream of logits row i is the one row row0 + i
+ * of a call on the whole batch would use (decoding a batch in independent parts, TF generation/utils.py:2921-2923). */
+int mgen_sample_rows(const void* logits, long ld, int B, int V, int is_bf16, int do_sample, float temperature,
+                     int top_k, float top_p, const float* noise, long ld_noise, unsigned long long seed,
+                     unsigned long long offset, int row0, long* out, long* out2, long out2_stride,
+                     mgen_stream_t stream);
 int mgen_philox_exponential(float* out, long ld, int B, int V, unsigned long long seed, unsigned long long offset,
                             mgen_stream_t stream);
 

@@ -104,6 +104,7 @@ struct SampleArgs {
     const float* noise; long ld_noise; unsigned long long seed, offset;
     long* out;
     long* out2; long out2_stride;  // optional second destination: out2[row * out2_stride]
+    unsigned row0;                 // Philox row index of logits row 0 (a call on rows [row0, row0 + B) of a larger batch)
 };
 
 // ---- generic kernel: one 1024-thread workgroup per row, every pass streams the row from cache ----------------
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(SampleArgs a) {
     for (int i = tid; i < V; i += NT) {
         const float s = ld_logit(row, i) / T;
         if (fkey(s) >= kcut) {
-            const float q = a.noise ? a.noise[(long)row_i * a.ld_noise + i] : philox_exp(a.seed, a.offset, row_i, i);
+            const float q = a.noise ? a.noise[(long)row_i * a.ld_noise + i] : philox_exp(a.seed, a.offset, a.row0 + row_i, i);
             const float sc = (__builtin_amdgcn_exp2f((s - smax) * c2) / Zk) / q;  // >= 0: its bits order like the value
             const unsigned long long p = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(~i);
             best = p > best ? p : best;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
             if (any4) {
                 const int i4 = (c * FNT + tid) * 8 + 4 * h;
                 unsigned w[4];
-                if (!a.noise) philox4(a.seed, a.offset, row_i, (unsigned)(i4 >> 2), w);
+                if (!a.noise) philox4(a.seed, a.offset, a.row0 + row_i, (unsigned)(i4 >> 2), w);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (k4[e] >= kcut) {
@@ -452,10 +453,13 @@ __global__ void philox_exp_kernel(float* __restrict__ out, long ld, int B, int V
 // logits [B][ld] (bf16 or fp32) -> out[B] int64. do_sample = 0: argmax. Otherwise temperature > 0, top_k (0 = off),
 // top_p in (0, 1] (1 = off); noise [B][ld_noise] fp32 Exp(1) draws, or null to use Philox(seed, offset).
 // out2 (may be null) receives the same ids at out2[b * out2_stride] (a column of the generated-sequence matrix).
-extern "C" int mgen_sample(const void* logits, long ld, int B, int V, int is_bf16, int do_sample, float temperature,
-                           int top_k, float top_p, const float* noise, long ld_noise, unsigned long long seed,
-                           unsigned long long offset, long* out, long* out2, long out2_stride, hipStream_t stream) {
-    MGEN_REQUIRE(logits && out && B > 0 && V > 0 && ld >= V, "mgen_sample: bad arguments");
+// row0: the rows are rows [row0, row0 + B) of a larger batch; the Philox stream of row i is that of row row0 + i of
+// one call on the whole batch (explicit noise is indexed from the pointer given).
+extern "C" int mgen_sample_rows(const void* logits, long ld, int B, int V, int is_bf16, int do_sample,
+                                float temperature, int top_k, float top_p, const float* noise, long ld_noise,
+                                unsigned long long seed, unsigned long long offset, int row0, long* out, long* out2,
+                                long out2_stride, hipStream_t stream) {
+    MGEN_REQUIRE(logits && out && B > 0 && V > 0 && ld >= V && row0 >= 0, "mgen_sample: bad arguments");
     if (do_sample) {
         MGEN_REQUIRE(temperature > 0.f, "mgen_sample: `temperature` (=%g) has to be a strictly positive float", temperature);
         MGEN_REQUIRE(top_p > 0.f && top_p <= 1.f, "mgen_sample: `top_p` has to be a float > 0 and <= 1, but is %g", top_p);
@@ -465,12 +469,19 @@ extern "C" int mgen_sample(const void* logits, long ld, int B, int V, int is_bf1
     SampleArgs a;
     a.logits = logits; a.ld = ld; a.V = V; a.temperature = temperature; a.top_k = top_k; a.top_p = top_p;
     a.do_sample = do_sample; a.noise = noise; a.ld_noise = ld_noise; a.seed = seed; a.offset = offset; a.out = out;
-    a.out2 = out2; a.out2_stride = out2_stride;
+    a.out2 = out2; a.out2_stride = out2_stride; a.row0 = (unsigned)row0;
     const bool fast = is_bf16 && V <= FAST_MAX_V && ld % 8 == 0 && ((uintptr_t)logits % 16) == 0;
     if (fast) hipLaunchKernelGGL(sample_bf16_kernel, dim3(B), dim3(FNT), 0, stream, a);
     else if (is_bf16) hipLaunchKernelGGL((sample_kernel<bf16>), dim3(B), dim3(NT), 0, stream, a);
     else hipLaunchKernelGGL((sample_kernel<float>), dim3(B), dim3(NT), 0, stream, a);
     return mgen_check_launch("mgen_sample");
+}
+
+extern "C" int mgen_sample(const void* logits, long ld, int B, int V, int is_bf16, int do_sample, float temperature,
+                           int top_k, float top_p, const float* noise, long ld_noise, unsigned long long seed,
+                           unsigned long long offset, long* out, long* out2, long out2_stride, hipStream_t stream) {
+    return mgen_sample_rows(logits, ld, B, V, is_bf16, do_sample, temperature, top_k, top_p, noise, ld_noise, seed,
+                            offset, 0, out, out2, out2_stride, stream);
 }
 
 // writes the Exp(1) draws mgen_sample would use for (seed, offset): out [B][ld]

@@ -85,6 +85,10 @@ SIGNATURES = {
     "mgen_scale_bf16": [P, L, F, P, P],
     "mgen_kv_append": [P, P, L, L, P, P, P, I, I, I, I, I, P],
     "mgen_attn_decode": [P, L, P, P, P, P, L, P, I, I, I, I, I, I, F, P],
+    "mgen_gemm_bf16_skinny": [P, P, P, I, I, I, L, L, L, I, L, I, P],
+    "mgen_decode_qkv_prep": [P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, I, P],
+    "mgen_attn_decode_prep": [P, L, P, P, P, P, F, I, P, P, P, P, L, P, I, I, I, I, I, I, F, P],
+    "mgen_sample_rows": [P, L, I, I, I, I, F, I, F, P, L, U64, U64, I, P, P, L, P],
     "mgen_sample": [P, L, I, I, I, I, F, I, F, P, L, U64, U64, P, P, L, P],
     "mgen_philox_exponential": [P, L, I, I, U64, U64, P],
 }
@@ -114,6 +118,8 @@ def lib():
         l.mgen_sumsq_partial_count.restype = ctypes.c_int
         l.mgen_gemm_slab_count.argtypes = [I, I]
         l.mgen_gemm_slab_count.restype = ctypes.c_int
+        l.mgen_gemm_skinny_fits.argtypes = [I, I, I, L, L, L, I]
+        l.mgen_gemm_skinny_fits.restype = ctypes.c_int
         l.mgen_attn_decode_workspace.argtypes = [I, I, I, I]
         l.mgen_attn_decode_workspace.restype = ctypes.c_long
         l.mgen_device_info.argtypes = [I, ctypes.c_char_p, I]

@@ -9,10 +9,14 @@ explicit top_k runs with top_k = 50.
 
 MI355X design: the cache is allocated once per call ([B, KVH, max_len, D] bf16 per layer, head-major so that a
 stream's keys are contiguous), every step runs M = B token rows through the same GEMM kernels as training plus the
-split-key decode-attention kernel, and the sampler kernel writes the new ids straight into the output matrix. The
+split-key decode-attention kernel, and the sampler kernel writes the new ids straight into the output matrix.
+Streams are independent, so a large batch is decoded as two halves on two HIP streams: a step is a chain of one long
+HBM-bound kernel per layer (the attention over the cache) and ~9 short latency-bound ones (projections at M = B rows,
+norms, sampler); with two chains in flight the short kernels of one half run under the attention of the other. The
 multinomial draw uses explicit Exp(1) noise (argmax p/q): a `noise` tensor [steps, B, V] for parity checks, or a
 counter-based Philox stream keyed by `seed` (offset = step).
 """
+import os
 from typing import Optional
 
 import torch
@@ -32,8 +36,31 @@ class KVCache:
         return 2 * len(self.k) * self.k[0].shape[1] * self.k[0].shape[3] * 2
 
 
+class _CachePart:
+    """Streams [b0, b1) of a KVCache (views: a stream's rows are contiguous)."""
+
+    def __init__(self, cache: KVCache, b0: int, b1: int):
+        self.max_len = cache.max_len
+        self.k = [t[b0:b1] for t in cache.k]
+        self.v = [t[b0:b1] for t in cache.v]
+
+
+class _Part:
+    """One independently decoded part of the batch: streams [b0, b1), its buffers, cache views and HIP stream."""
+
+    def __init__(self, cfg, cache, b0, b1, nxt, ws_floats, dev, stream):
+        self.b0, self.b1, self.stream = b0, b1, stream
+        self.cache = _CachePart(cache, b0, b1)
+        self.buf = _DecodeBuffers(cfg, b1 - b0, dev, nxt[b0:b1])
+        self.ws = torch.empty(max(ws_floats, 1), dtype=torch.float32, device=dev)
+
+
+# batches of at least this many streams are decoded as two halves on two HIP streams (MGEN_DECODE_PARTS=1: never)
+_TWO_PART_MIN_STREAMS = 64
+
+
 class _DecodeBuffers:
-    def __init__(self, cfg, B, dev):
+    def __init__(self, cfg, B, dev, nxt=None):
         bf, f32 = torch.bfloat16, torch.float32
         d, I = cfg.hidden_size, cfg.intermediate_size
         H, KVH, Dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -48,10 +75,18 @@ class _DecodeBuffers:
         self.act = torch.empty(B, I, dtype=bf, device=dev)
         self.ldv = (cfg.vocab_size + 7) // 8 * 8
         self.logits = torch.empty(B, self.ldv, dtype=bf, device=dev)
-        self.next = torch.empty(B, dtype=torch.int64, device=dev)
+        self.next = nxt if nxt is not None else torch.empty(B, dtype=torch.int64, device=dev)
+        # The four projections of a layer run on the one-round-trip kernel for few token rows when their shapes
+        # fit it (512-long reduction slices); the down projection then forms silu(gate) * up while it loads gu.
+        NQ, HD = cfg.qkv_width, H * Dh
+        sk = not cfg.pos4d
+        self.sk_qkv = sk and ops.skinny_fits(B, NQ, d, d, d, NQ, False)
+        self.sk_gu = sk and ops.skinny_fits(B, 2 * I, d, d, d, 2 * I, False)
+        self.sk_o = sk and ops.skinny_fits(B, d, HD, HD, HD, d, True)
+        self.sk_down = sk and ops.skinny_fits(B, d, I, 2 * I, I, d, True)
         # split-K slabs of the two residual projections (K = H*Dh and K = I)
-        self.ns_o = ops.gemm_slab_count(H * Dh)
-        self.ns_d = ops.gemm_slab_count(I)
+        self.ns_o = HD // 512 if self.sk_o else ops.gemm_slab_count(HD)
+        self.ns_d = I // 512 if self.sk_down else ops.gemm_slab_count(I)
         self.slabs = torch.empty(max(self.ns_o, self.ns_d), B, d, dtype=f32, device=dev)
         if cfg.pos4d:
             self.rot = torch.empty(B, cfg.qkv_width, dtype=bf, device=dev)
@@ -69,46 +104,70 @@ class GenerationMixin:
         want = max(1, 1024 // max(blocks, 1))
         return max(1, min(64, want, (length + 255) // 256))
 
-    def _decode_step(self, tokens, cache: KVCache, t: int, buf: _DecodeBuffers, lens, ws):
-        """One token per stream at position t (all streams share t); returns bf16 logits [B, ldv]."""
+    def _decode_begin(self, tokens, buf: _DecodeBuffers):
+        """Start of a one-token step: embedding row per stream and the first layer's input norm."""
+        ops.embedding_fwd(tokens, self.model.embed_tokens.weight, buf.h0, self._err_flag)
+        ops.rmsnorm_fwd(buf.h0, self._layers[0].w_ln1, buf.x, None, self.cfg.rms_norm_eps)
+        buf.h = buf.h0
+
+    def _decode_layer(self, l: int, cache, t: int, buf: _DecodeBuffers, lens, ws):
+        """Decoder layer l of a one-token step at position t (all streams share t). The residual stream is in buf.h,
+        the normed input of the layer in buf.x."""
         cfg = self.cfg
-        B = tokens.shape[0]
+        B = buf.x.shape[0]
         d, H, KVH, Dh, I = (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
                             cfg.intermediate_size)
         NQ, QK = cfg.qkv_width, (H + KVH) * Dh
-        cs = self._rope_table(t + 1)
-        scale = Dh ** -0.5
-        pos = lens[t]          # int32 [B] = t
-        kv_len = lens[t + 1]   # int32 [B] = t + 1
-        nsplit = self._decode_split(B, t + 1)
-        h = buf.h0
         eps = cfg.rms_norm_eps
         L = cfg.num_hidden_layers
-        ops.embedding_fwd(tokens, self.model.embed_tokens.weight, h, self._err_flag)
-        ops.rmsnorm_fwd(h, self._layers[0].w_ln1, buf.x, None, eps)
+        v = self._layers[l]
+        pos = lens[t]          # int32 [>= B] = t
+        kv_len = lens[t + 1]   # int32 [>= B] = t + 1
+        h = buf.h
+        if buf.sk_qkv:
+            ops.linear_skinny(buf.x, v.s_qkv, buf.qkv)
+        else:
+            ops.linear_fwd(buf.x, v.s_qkv, buf.qkv)
+        # attention over the cache; q/k norm + rotation of the new token and its cache append happen in the same launch
+        ops.attn_decode_prep(buf.qkv, NQ, v.w_qn, v.w_kn, self._rope_cs, pos, eps, cfg.rope_interleaved, cache.k[l],
+                             cache.v[l], kv_len, buf.att, H * Dh, ws, B, H, KVH, Dh, cache.max_len,
+                             self._decode_split(B, t + 1), Dh ** -0.5)
         # The two residual projections have few output tiles at M = B rows: they run split along K into fp32 slabs,
         # and one kernel sums the slabs, adds the residual and applies the norm that follows.
-        for l, v in enumerate(self._layers):
-            ops.linear_fwd(buf.x, v.s_qkv, buf.qkv)
-            qp = buf.qk.data_ptr()
-            ops.qknorm_rope_fwd(buf.qkv, NQ, qp, qp + 2 * H * Dh, QK, QK, v.w_qn, v.w_kn, cs, pos, 1, B, H, KVH, Dh, eps,
-                                interleaved=cfg.rope_interleaved)
-            ops.kv_append(qp + 2 * H * Dh, buf.qkv.data_ptr() + 2 * QK, QK, NQ, cache.k[l], cache.v[l], pos, B, 1, KVH,
-                          Dh, cache.max_len)
-            ops.attn_decode(qp, QK, cache.k[l], cache.v[l], kv_len, buf.att, H * Dh, ws, B, H, KVH, Dh, cache.max_len,
-                            nsplit, scale)
+        if buf.sk_o:
+            ops.linear_skinny(buf.att, v.s_o, buf.slabs, slabs=True)
+        else:
             ops.linear_slabs(buf.att, v.s_o, buf.slabs, buf.ns_o)
-            ops.slab_resid_rmsnorm(buf.slabs, buf.ns_o, h, buf.h1, v.w_ln2, buf.x, eps)
+        ops.slab_resid_rmsnorm(buf.slabs, buf.ns_o, h, buf.h1, v.w_ln2, buf.x, eps)
+        if buf.sk_gu:
+            ops.linear_skinny(buf.x, v.s_gu, buf.gu)
+        else:
             ops.linear_fwd(buf.x, v.s_gu, buf.gu)
+        if buf.sk_down:
+            ops.linear_skinny(buf.gu, v.s_down, buf.slabs, slabs=True, a_swiglu=True)
+        else:
             ops.swiglu_fwd(buf.gu, buf.act)
             ops.linear_slabs(buf.act, v.s_down, buf.slabs, buf.ns_d)
-            nxt = buf.h2 if h is buf.h0 else buf.h0
-            w_next = self._layers[l + 1].w_ln1 if l + 1 < L else self.model.norm.weight
-            ops.slab_resid_rmsnorm(buf.slabs, buf.ns_d, buf.h1, nxt, w_next, buf.x, eps)
-            h = nxt
+        nxt = buf.h2 if h is buf.h0 else buf.h0
+        w_next = self._layers[l + 1].w_ln1 if l + 1 < L else self.model.norm.weight
+        ops.slab_resid_rmsnorm(buf.slabs, buf.ns_d, buf.h1, nxt, w_next, buf.x, eps)
+        buf.h = nxt
+
+    def _decode_end(self, buf: _DecodeBuffers):
+        """lm_head on the final-normed rows; returns bf16 logits [B, ldv]."""
+        cfg = self.cfg
         W = self._view(self.flat_shadow, self._lm_head_name())
-        ops.gemm(buf.x, W, buf.logits, B, cfg.vocab_size, d, d, W.stride(0), buf.ldv)
+        ops.gemm(buf.x, W, buf.logits, buf.x.shape[0], cfg.vocab_size, cfg.hidden_size, cfg.hidden_size, W.stride(0),
+                 buf.ldv)
         return buf.logits
+
+    def _decode_step(self, tokens, cache: KVCache, t: int, buf: _DecodeBuffers, lens, ws):
+        """One token per stream at position t (all streams share t); returns bf16 logits [B, ldv]."""
+        self._rope_table(t + 1)
+        self._decode_begin(tokens, buf)
+        for l in range(self.cfg.num_hidden_layers):
+            self._decode_layer(l, cache, t, buf, lens, ws)
+        return self._decode_end(buf)
 
     @torch.no_grad()
     def generate(self, input_ids=None, max_new_tokens: Optional[int] = None, max_length: Optional[int] = None,
@@ -178,41 +237,88 @@ class GenerationMixin:
             self._check_device_flags()
             return (out, torch.stack(step_logits, 0)) if return_step_logits else out
         cache = KVCache(cfg, B, total, dev)
-        buf = _DecodeBuffers(cfg, B, dev)
         # lens[t] = int32 [B] filled with t: per-stream positions / key counts without per-step host->device traffic
         lens = torch.arange(total + 1, dtype=torch.int32, device=dev)[:, None].expand(total + 1, B).contiguous()
-        max_split = self._decode_split(B, total)
-        ws_n = ops.attn_decode_workspace(B, cfg.num_attention_heads, cfg.head_dim, max_split)
-        ws = torch.empty(max(ws_n, 1), dtype=torch.float32, device=dev)
+        self._rope_table(total)          # sized once, before any side stream reads it
+        nparts = 2 if (B >= _TWO_PART_MIN_STREAMS and os.environ.get("MGEN_DECODE_PARTS", "2") != "1") else 1
+        main = torch.cuda.current_stream()
+        nxt_all = torch.empty(B, dtype=torch.int64, device=dev)
+        parts = []
+        for i in range(nparts):
+            b0, b1 = B * i // nparts, B * (i + 1) // nparts
+            ws_n = ops.attn_decode_workspace(b1 - b0, cfg.num_attention_heads, cfg.head_dim,
+                                             self._decode_split(b1 - b0, total))
+            parts.append(_Part(cfg, cache, b0, b1, nxt_all, ws_n, dev,
+                               main if nparts == 1 else torch.cuda.Stream(device=dev)))
         unfinished = torch.ones(B, dtype=torch.int64, device=dev) if eos_token_id is not None else None
-        step_logits = [] if return_step_logits else None
+        step_logits = [[] for _ in parts] if return_step_logits else None
 
-        def pick(logits, step):
-            nz = noise[step] if (noise is not None and do_sample) else None
-            col = out.data_ptr() + 8 * (P + step)
-            ops.sample(logits, V, buf.next, do_sample, temperature, top_k or 0, top_p, nz, seed, step,
-                       out2=None if unfinished is not None else col, out2_stride=total)
-            if return_step_logits:
-                step_logits.append(logits[:, :V].float().clone())
+        def pick(logits, step, b0, b1, nxt, log=None):
+            """Rows [b0, b1) of the batch: choose the token of generation step `step` from their logits."""
+            nz = noise[step][b0:b1] if (noise is not None and do_sample) else None
+            col = out.data_ptr() + 8 * (b0 * total + P + step)
+            ops.sample(logits, V, nxt, do_sample, temperature, top_k or 0, top_p, nz, seed, step,
+                       out2=None if unfinished is not None else col, out2_stride=total, row0=b0)
+            if log is not None:
+                log.append(logits[:, :V].float().clone())
             if unfinished is not None:
-                tok = buf.next * unfinished + pad_token_id * (1 - unfinished)
-                buf.next.copy_(tok)
-                out[:, P + step] = tok
-                unfinished.mul_((tok != eos_token_id).long())
+                unf = unfinished[b0:b1]
+                tok = nxt * unf + pad_token_id * (1 - unf)
+                nxt.copy_(tok)
+                out[b0:b1, P + step] = tok
+                unf.mul_((tok != eos_token_id).long())
 
         # ---- prefill: the training forward on the prompt, K/V written into the cache
         xN, _ = self._run_layers(input_ids.contiguous(), save=None, cache=cache)
         last = xN.view(B, P, -1)[:, -1, :].contiguous()
         W = self._view(self.flat_shadow, self._lm_head_name())
-        ops.gemm(last, W, buf.logits, B, V, cfg.hidden_size, last.stride(0), W.stride(0), buf.ldv)
-        pick(buf.logits, 0)
+        ldv = parts[0].buf.ldv
+        logits0 = parts[0].buf.logits if nparts == 1 else torch.empty(B, ldv, dtype=torch.bfloat16, device=dev)
+        ops.gemm(last, W, logits0, B, V, cfg.hidden_size, last.stride(0), W.stride(0), ldv)
+        for i, pt in enumerate(parts):
+            pick(logits0[pt.b0:pt.b1], 0, pt.b0, pt.b1, pt.buf.next, step_logits[i] if return_step_logits else None)
+        if nparts > 1:
+            for pt in parts:
+                pt.stream.wait_stream(main)
         n_done = 1
+        L = cfg.num_hidden_layers
         for step in range(1, max_new_tokens):
-            if unfinished is not None and step % eos_check_every == 0 and int(unfinished.max()) == 0:
-                break
-            logits = self._decode_step(buf.next, cache, P + step - 1, buf, lens, ws)
-            pick(logits, step)
+            if unfinished is not None and step % eos_check_every == 0:
+                if nparts > 1:
+                    for pt in parts:
+                        main.wait_stream(pt.stream)
+                if int(unfinished.max()) == 0:
+                    break
+            t = P + step - 1
+            if nparts == 1:
+                pt = parts[0]
+                logits = self._decode_step(pt.buf.next, pt.cache, t, pt.buf, lens, pt.ws)
+                pick(logits, step, 0, B, pt.buf.next, step_logits[0] if return_step_logits else None)
+            else:
+                # The launches of the two halves are issued layer by layer in turn, each half on its own stream.
+                # (Chaining the attention launches of the two halves through events, so that they never run at the
+                # same time, measured slower than leaving the two streams alone: 5.68 against 5.45 ms per step.)
+                try:
+                    for pt in parts:
+                        ops.use_stream(pt.stream.cuda_stream)
+                        self._decode_begin(pt.buf.next, pt.buf)
+                    for l in range(L):
+                        for pt in parts:
+                            ops.use_stream(pt.stream.cuda_stream)
+                            self._decode_layer(l, pt.cache, t, pt.buf, lens, pt.ws)
+                    for pt in parts:
+                        ops.use_stream(pt.stream.cuda_stream)
+                        self._decode_end(pt.buf)
+                finally:
+                    ops.use_stream(None)
+                for i, pt in enumerate(parts):
+                    with torch.cuda.stream(pt.stream):
+                        pick(pt.buf.logits, step, pt.b0, pt.b1, pt.buf.next,
+                             step_logits[i] if return_step_logits else None)
             n_done = step + 1
+        if nparts > 1:
+            for pt in parts:
+                main.wait_stream(pt.stream)
         if unfinished is not None and n_done < max_new_tokens:
             out = out[:, :P + n_done]
         if unfinished is not None:
@@ -224,7 +330,8 @@ class GenerationMixin:
                 out = out[:, :P + first + 1]
         self._check_device_flags()
         if return_step_logits:
-            return out, torch.stack(step_logits, 0)
+            n = min(len(x) for x in step_logits)
+            return out, torch.cat([torch.stack(x[:n], 0) for x in step_logits], 1)
         return out
 
     # ------------------------------------------------------------------------------------------------

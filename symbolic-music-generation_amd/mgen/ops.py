@@ -12,8 +12,18 @@ OUT_BF16, OUT_F32, OUT_F32_ACC, OUT_F32_RESID_BF16ROUND, OUT_F32_RESID = 0, 1, 2
 OUT_BF16_ACC = 6   # bf16 C = bf16(C + product)
 
 
+_stream_override = None
+
+
+def use_stream(handle):
+    """Launch on this raw HIP stream handle instead of torch's current stream (None: back to torch's). For code that
+    feeds several streams in turn without switching torch's stream context for every launch."""
+    global _stream_override
+    _stream_override = handle
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _stream_override if _stream_override is not None else torch.cuda.current_stream().cuda_stream
 
 
 def _p(t):
@@ -107,6 +117,22 @@ def linear_slabs(x, w, slabs, nslabs):
     T, K = x.shape
     N = w.shape[0]
     call("mgen_gemm_bf16_slabs", _p(x), _p(w), _p(slabs), T, N, K, x.stride(0), w.stride(0), 0, 0, nslabs, _stream())
+
+
+def skinny_fits(M, N, K, lda, ldw, ldc, slabs):
+    from ._lib import lib
+    return os.environ.get("MGEN_GEMM_SKINNY", "1") != "0" and bool(lib().mgen_gemm_skinny_fits(M, N, K, lda, ldw, ldc,
+                                                                                                int(slabs)))
+
+
+def linear_skinny(x, w, out, slabs=False, a_swiglu=False):
+    """Decode-step projection out = x @ w^T (x [M, K] bf16, or gu [M, 2K] with a_swiglu: the operand is
+    silu(gate) * up); out bf16 [M, N], or with slabs fp32 [K / 512, M, N] partial products."""
+    _need_gpu(x, w, out)
+    M = x.shape[0]
+    N, K = w.shape
+    call("mgen_gemm_bf16_skinny", _p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), N, int(slabs),
+         M * N, int(a_swiglu), _stream())
 
 
 def slab_resid_rmsnorm(slabs, nslabs, resid, h_out, w, y, eps, round_bf16=True):
@@ -519,18 +545,33 @@ def attn_decode(q, ld_q, k_cache, v_cache, kv_len, out, ld_o, workspace, B, H, K
          max_len, nsplit, scale, _stream())
 
 
+def attn_decode_prep(qkv, ld_in, wq, wk, cs, pos, eps, interleaved, k_cache, v_cache, kv_len, out, ld_o, workspace, B, H,
+                     KVH, D, max_len, nsplit, scale):
+    """decode_qkv_prep + attn_decode in one launch (q, new key and value taken from the raw projection rows)."""
+    call("mgen_attn_decode_prep", _p(qkv), ld_in, _p(wq), _p(wk), _p(cs), _p(pos), eps, int(interleaved), _p(k_cache),
+         _p(v_cache), _p(kv_len), _p(out), ld_o, _p(workspace), B, H, KVH, D, max_len, nsplit, scale, _stream())
+
+
 def attn_decode_workspace(B, H, D, nsplit):
     from ._lib import lib
     return lib().mgen_attn_decode_workspace(B, H, D, nsplit)
 
 
 def sample(logits, V, out, do_sample=False, temperature=1.0, top_k=0, top_p=1.0, noise=None, seed=0, offset=0,
-           out2=None, out2_stride=0):
-    """logits [B, ld] (bf16 or fp32) -> out [B] int64; out2 = raw pointer of an optional strided second destination."""
+           out2=None, out2_stride=0, row0=0):
+    """logits [B, ld] (bf16 or fp32) -> out [B] int64; out2 = raw pointer of an optional strided second destination.
+    row0: the rows are rows [row0, row0 + B) of a larger batch (Philox stream of row i = that of row row0 + i)."""
     B = logits.shape[0]
-    call("mgen_sample", _p(logits), logits.stride(0), B, V, int(logits.dtype == torch.bfloat16), int(do_sample),
+    call("mgen_sample_rows", _p(logits), logits.stride(0), B, V, int(logits.dtype == torch.bfloat16), int(do_sample),
          float(temperature), int(top_k or 0), float(top_p), _p(noise), noise.stride(0) if noise is not None else 0,
-         int(seed), int(offset), _p(out), out2 or 0, out2_stride, _stream())
+         int(seed), int(offset), int(row0), _p(out), out2 or 0, out2_stride, _stream())
+
+
+def decode_qkv_prep(qkv, ld_in, qout, ld_q, k_cache, v_cache, wq, wk, cs, pos, B, HQ, HK, D, max_len, eps,
+                    interleaved=False):
+    """One decode step: q/k norm + rotation, q to `qout` (raw pointer), k and v into their cache slots."""
+    call("mgen_decode_qkv_prep", _p(qkv), ld_in, qout, ld_q, _p(k_cache), _p(v_cache), _p(wq), _p(wk), _p(cs),
+         _p(pos), B, HQ, HK, D, max_len, eps, int(interleaved), _stream())
 
 
 def philox_exponential(out, V, seed, offset):

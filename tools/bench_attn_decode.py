@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
 from mgen import ops  # noqa: E402
 
-B, H, KVH, D = 256, 8, 8, 128
+B, H, KVH, D = int(os.environ.get("STREAMS", "256")), 8, 8, 128
 dev = "cuda"
 lens = [int(a) for a in sys.argv[1:]] or [1920]
 for max_len in [int(x) for x in os.environ.get("MAXLEN", "2048").split(",")]:
@@ -19,7 +19,7 @@ for max_len in [int(x) for x in os.environ.get("MAXLEN", "2048").split(",")]:
     out = torch.empty(B, H * D, device=dev, dtype=torch.bfloat16)
     for L in lens:
         kv_len = torch.full((B,), L, dtype=torch.int32, device=dev)
-        for nsplit in (1, 2, 4):
+        for nsplit in [int(x) for x in os.environ.get("NSPLIT", "1,2,4").split(",")]:
             ws = torch.empty(max(1, ops.attn_decode_workspace(B, H, D, nsplit)), dtype=torch.float32, device=dev)   # counted in floats
             f = lambda: ops.attn_decode(q.data_ptr(), H * D, k, v, kv_len, out, H * D, ws, B, H, KVH, D, max_len, nsplit,
                                         D ** -0.5)

@@ -1,0 +1,29 @@
+"""Decode-only benchmark (GPU box): bench.py's two decode legs without the training step.
+   python tools/bench_decode.py [repeats]      env: MGEN_DECODE_PARTS, MGEN_DECODE_CHAIN, MGEN_GEMM_SKINNY"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from mgen import MidiLM, default_decoder  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = default_decoder()
+model = MidiLM(cfg, device=dev, seed=0)
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 1):
+    legs = os.environ.get("LEGS", "literal,long").split(",")
+    msg = []
+    if "literal" in legs:
+        a = bench.bench_decode(model, cfg, 256, 1, 4095, dev)
+        msg.append(f"literal {a['ms_per_step']:.3f} ms/step frac {a['hbm_frac']:.4f}")
+    if "long" in legs:
+        b = bench.bench_decode(model, cfg, 256, 1792, 256, dev)
+        msg.append(f"long context {b['ms_per_step']:.3f} frac {b['hbm_frac']:.4f}")
+    if "short" in legs:
+        c = bench.bench_decode(model, cfg, 256, 1, 512, dev)
+        msg.append(f"contexts 1-512 {c['ms_per_step']:.3f}")
+    print(" | ".join(msg), flush=True)

@@ -45,7 +45,23 @@ def report(path):
         t[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     span = int(dec[-1]["End_Timestamp"]) - int(dec[0]["Start_Timestamp"])
     busy = sum(v[1] for v in tot.values())
-    print(f"decode steps {steps}; wall {span / steps / 1e3:.1f} us/step; kernel time {busy / steps / 1e3:.1f} us/step")
+    # timeline: time with at least one / at least two kernels running (two-part decoding overlaps the parts)
+    ev = []
+    for r in dec:
+        ev.append((int(r["Start_Timestamp"]), 1))
+        ev.append((int(r["End_Timestamp"]), -1))
+    ev.sort()
+    depth, prev, one, two = 0, ev[0][0], 0, 0
+    for ts, dlt in ev:
+        if depth >= 1:
+            one += ts - prev
+        if depth >= 2:
+            two += ts - prev
+        depth += dlt
+        prev = ts
+    print(f"decode steps {steps}; wall {span / steps / 1e3:.1f} us/step; kernel time {busy / steps / 1e3:.1f} us/step; "
+          f"some kernel running {one / steps / 1e3:.1f} us/step (idle {(span - one) / steps / 1e3:.1f}); "
+          f">= 2 kernels running {two / steps / 1e3:.1f} us/step")
     for k, (n, ns) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
         print(f"{ns / steps / 1e3:9.1f} us/step  {n / steps:6.1f} launches/step  {ns / n / 1e3:8.1f} us avg  {k}")
 
