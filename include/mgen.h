@@ -399,6 +399,10 @@ int mgen_philox_exponential(float* out, long ld, int B, int V, unsigned long lon
  *                           communicator's own stream behind what compute_stream holds now; returns at once
  *   mgen_comm_wait          makes `stream` wait for every bucket enqueued so far; optional outputs: bytes and buckets
  *                           reduced since the previous wait
+ *                           reduced since the previous wait. Both calls first ask RCCL for an asynchronous error of the
+ *                           communicator (a rank that died, a link failure): then the communicator is aborted, which
+ *                           unblocks the collectives still queued, and the call fails instead of hanging
+ *   mgen_comm_abort         gives up on the communicator (ncclCommAbort); later calls on it fail
  *   mgen_comm_rccl_version  the RCCL version code (e.g. 22205) */
 typedef struct mgen_comm mgen_comm_t;
 int mgen_comm_unique_id(void* id128);
@@ -406,6 +410,7 @@ int mgen_comm_rccl_version(int* version);
 int mgen_comm_init(mgen_comm_t** comm, const void* id128, int rank, int world, int device);
 int mgen_comm_allreduce_bucket(mgen_comm_t* comm, float* buf, long n, int average, mgen_stream_t compute_stream);
 int mgen_comm_wait(mgen_comm_t* comm, mgen_stream_t stream, long* bytes, int* buckets);
+int mgen_comm_abort(mgen_comm_t* comm);
 int mgen_comm_destroy(mgen_comm_t* comm);
 
 #ifdef __cplusplus

@@ -316,7 +316,8 @@ extern "C" int mgen_ce_fwd_bwd(void* logits, const long* labels, long tok0, long
     const dim3 grid((unsigned)rows), block(256);
     const int nvec = (V + 7) / 8;
     static const int row_env = [] { const char* e = getenv("MGEN_CE_ROW"); return e ? atoi(e) : 1; }();
-    if (is_bf16 && row_env && nvec > 2048 && nvec <= 512 * 38) {
+    // (the row kernel folds the gradient scale into its exponent as log2(g): a negative scale takes the other kernel)
+    if (is_bf16 && row_env && grad_scale >= 0.f && nvec > 2048 && nvec <= 512 * 38) {
         // long bf16 rows (the 151,936-entry vocabulary): one 512-thread block keeps the row in registers
         // one resident block per CU (the row fills the register file), each walking rows grid-stride
         static const int ncu = [] {

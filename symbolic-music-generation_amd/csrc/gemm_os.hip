@@ -606,6 +606,14 @@ extern "C" int mgen_gemm_bf16_wgrad_group(int n, const void* const* A, const voi
     const int maxsk = steps / 32;
     if (sk > maxsk) sk = maxsk;
     if (sk < 1) sk = 1;
+    {   // at least as many slices as keep a slice of the widest operand below 4 GiB (32-bit buffer offsets)
+        long ldmax = 8;
+        for (int i = 0; i < n; ++i) ldmax = lda[i] > ldmax ? lda[i] : (ldb[i] > ldmax ? ldb[i] : ldmax);
+        for (int i = 0; i < n; ++i) ldmax = ldb[i] > ldmax ? ldb[i] : ldmax;
+        const long max_rows = ((1L << 32) - 1) / (ldmax * 2) / OS_BK * OS_BK;
+        const int need = (int)((K + max_rows - 1) / max_rows);
+        if (sk < need) sk = need;
+    }
     const int per = (steps + sk - 1) / sk;
     const int splitk = (steps + per - 1) / per;
     for (int i = 0; i < n; ++i) { gg.p[i].kper = per * OS_BK; gg.p[i].splitk = splitk; }

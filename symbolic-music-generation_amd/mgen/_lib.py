@@ -48,6 +48,7 @@ SIGNATURES = {
     "mgen_comm_init": [P, P, I, I, I],
     "mgen_comm_allreduce_bucket": [P, P, L, I, P],
     "mgen_comm_wait": [P, P, P, P],
+    "mgen_comm_abort": [P],
     "mgen_comm_destroy": [P],
     "mgen_embedding_fwd": [P, P, P, L, I, L, P, P],
     "mgen_embedding_bwd": [P, P, P, L, I, L, P],

@@ -203,8 +203,7 @@ class GenerationMixin:
         dev = input_ids.device
         V = cfg.vocab_size
         total = P + max_new_tokens
-        if self._err_flag is not None:
-            self._err_flag.zero_()   # bits left behind by an earlier call belong to that call
+        self._check_device_flags()   # bits an earlier call left behind (a forward whose backward never ran) are raised
         self.sync_shadow()
         out = torch.empty(B, total, dtype=torch.int64, device=dev)
         out[:, :P] = input_ids

@@ -155,6 +155,12 @@ class MidiLM(GenerationMixin, nn.Module):
         # device-side error bits raised by kernels: 1 = token id out of range, 2 = attention_mask is not right
         # padding, 4 = label outside [0, V). Read (one synchronisation) and cleared by _check_device_flags.
         self._err_flag = torch.zeros(1, dtype=torch.int32, device=dev) if dev.type == "cuda" else None
+        # defer_input_checks: backward does not wait for the device to read the error bits; it starts a copy of them
+        # to the host, and raise_pending_errors() (called by the Trainer once the optimizer step is queued) raises.
+        # A step loop then never stalls the host between backward and the optimizer, and under data parallelism
+        # every rank has issued its collectives before one of them raises.
+        self.defer_input_checks = False
+        self._err_pending = None      # (pinned host copy, event) of a deferred check
         if seed is not None:
             self.init_weights(seed)
 
@@ -185,6 +191,32 @@ class MidiLM(GenerationMixin, nn.Module):
         if self._err_flag is None:
             return
         bits = int(self._err_flag)
+        self._raise_for_bits(bits)
+
+    def _check_device_flags_deferred(self):
+        """End of backward with defer_input_checks: start the copy of the error bits, do not wait."""
+        if self._err_flag is None:
+            return
+        if not self.defer_input_checks:
+            return self._check_device_flags()
+        if self._err_pending is None:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._err_pending = [host, torch.cuda.Event(), False]
+        host, ev, _ = self._err_pending
+        host.copy_(self._err_flag, non_blocking=True)
+        ev.record()
+        self._err_pending[2] = True
+
+    def raise_pending_errors(self):
+        """Raise what a deferred check found (waits for the copy started at the end of backward)."""
+        if self._err_pending is None or not self._err_pending[2]:
+            return
+        host, ev, _ = self._err_pending
+        ev.synchronize()
+        self._err_pending[2] = False
+        self._raise_for_bits(int(host))
+
+    def _raise_for_bits(self, bits):
         if bits == 0:
             return
         self._err_flag.zero_()
@@ -201,12 +233,19 @@ class MidiLM(GenerationMixin, nn.Module):
         while the previous graph has not run its backward yet (two losses summed before one backward) gets a
         buffer of its own."""
         owner = self._lm_grad_owner() if self._lm_grad_owner is not None else None
+        if getattr(self, "_head_grad_sink", None) is not None and self._lm_grad_busy():
+            return torch.empty(shape, dtype=torch.float32, device=self.flat_param.device)
         if owner is not None and not owner.done:
             return torch.empty(shape, dtype=torch.float32, device=self.flat_param.device)
         if self._lm_grad_tmp is None or tuple(self._lm_grad_tmp.shape) != tuple(shape):
             self._lm_grad_tmp = torch.empty(shape, dtype=torch.float32, device=self.flat_param.device)
         self._lm_grad_owner = weakref.ref(token)
         return self._lm_grad_tmp
+
+    def _lm_grad_busy(self):
+        """True while a gradient reducer still holds the shared head-gradient buffer of an earlier backward."""
+        busy = getattr(self, "_head_grad_in_flight", None)
+        return bool(busy and busy())
 
     def _anchor(self):
         """A parameter handed to the autograd node so that it has a differentiable input."""
@@ -856,12 +895,21 @@ class _LMTrainFunction(torch.autograd.Function):
             ops.scale_bf16_(dxN, 1.0, go)
         if ctx.lm_grad is not None:   # (frozen base: the head's weight gradient was not formed)
             name = model._lm_head_name()
-            ops.axpy_(model._view(model.flat_grad, name).view(-1), ctx.lm_grad.view(-1), 1.0, go)
+            sink = getattr(model, "_head_grad_sink", None)
+            if sink is not None and model.cfg.tie_word_embeddings and not model.cfg.pos4d:
+                # data parallel, tied head: the head's weight gradient is final NOW, at the start of backward, while
+                # the embedding lookup's share of the same tensor only arrives at its end. It is handed over as a
+                # gradient bucket of its own (reduced under the whole backward) and added to the reduced embedding
+                # share by whoever took it.
+                ops.scale_(ctx.lm_grad.view(-1), 1.0, go)
+                sink(ctx.lm_grad, model._view(model.flat_grad, name))
+            else:
+                ops.axpy_(model._view(model.flat_grad, name).view(-1), ctx.lm_grad.view(-1), 1.0, go)
         model._backward_layers(ctx.input_ids, ctx.saved, ctx.final, dxN, getattr(model, "_grad_hook", None))
         ctx.saved = None
         ctx.lm_grad = None
         ctx.token.done = True
-        model._check_device_flags()
+        model._check_device_flags_deferred()
         for pname, prm in model.named_parameters():
             if prm.grad is None:
                 prm.grad = model._view(model.flat_grad, pname)

@@ -40,8 +40,18 @@ class GradReducer:
             from .comm import NativeComm
             self._comm = NativeComm(group=group)
         self._lora = getattr(model, "lora", None)   # adapters: one small buffer, reduced in wait()
+        # Tied embedding / head: the head's weight gradient arrives as a buffer of its own at the START of backward
+        # (first bucket, reduced under the whole backward); the embedding lookup's scatter-add stays the last bucket,
+        # cut down to the rows [0, embed_rows) that any rank's batch can have touched (set_embed_rows).
+        self._tied = []            # (reduced head-gradient buffer, destination view) of this step
+        self._embed_rows = None    # () -> row count, or None: the whole table
+        self._max_host = self._max_event = None
         if self.world > 1 and self._lora is None:
             model._grad_hook = self._on_range_done
+            if hasattr(model, "_lm_head_name") and getattr(model.cfg, "tie_word_embeddings", False) \
+                    and os.environ.get("MGEN_DDP_SPLIT_TIED", "1") != "0":
+                model._head_grad_sink = self._on_head_grad
+                model._head_grad_in_flight = lambda: bool(self._tied)
 
     def _flush(self):
         if self._open is None:
@@ -72,8 +82,53 @@ class GradReducer:
             return _Done()
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _on_head_grad(self, buf, dest):
+        flat = buf.view(-1)
+        self.bucket_log.append((flat.numel() * flat.element_size(), str(flat.dtype).replace("torch.", "")))
+        self._pending.append((self._start(flat), flat))
+        self._tied.append((buf, dest))
+
+    def note_token_ids(self, ids):
+        """Call at the start of a step with this rank's input ids. With a tied head, the largest token id over all
+        ranks bounds the embedding rows whose lookup gradient can be non-zero, so the last gradient bucket (the only
+        one nothing overlaps) shrinks from the whole [V, d] table to those rows (the reference's default decoder
+        keeps a 151 936-row table for token ids below 30 000). The maximum is reduced now and read when the bucket
+        is sent."""
+        if self.world <= 1 or ids is None or getattr(self.model, "_head_grad_sink", None) is None:
+            return
+        mx = ids.max().to(torch.int64).reshape(1)
+        if self._native_avg:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+            if self._max_host is None:
+                self._max_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+                self._max_event = torch.cuda.Event()
+            self._max_host.copy_(mx, non_blocking=True)
+            self._max_event.record()
+
+            def rows():
+                self._max_event.synchronize()
+                return int(self._max_host) + 1
+        else:   # gloo rehearsal: staged through the host
+            host = mx.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            val = int(host) + 1
+
+            def rows():
+                return val
+        self.set_embed_rows(rows)
+
+    def set_embed_rows(self, fn):
+        """fn() -> number of leading embedding rows that can hold a lookup gradient on ANY rank (the same number on
+        every rank), or None. Called when the embedding bucket is about to be sent."""
+        self._embed_rows = fn
+
     def _on_range_done(self, tag):
         s, e = self._ranges[tag]
+        if tag == "embed" and self._tied and self._embed_rows is not None:
+            rows = self._embed_rows()
+            if rows is not None:
+                d = self._tied[0][1].shape[1]
+                e = min(e, s + int(rows) * d)
         if self._open is not None and self._open[0] == e:
             self._open[0] = s          # ranges are adjacent and arrive in descending address order
         else:
@@ -91,11 +146,20 @@ class GradReducer:
             self.bucket_log.append((buf.numel() * buf.element_size(), str(buf.dtype).replace("torch.", "")))
             self._pending.append((self._start(buf), buf))
         self._flush()
+        waited_comm = False
         for w, buf in self._pending:
-            w.wait()
+            if w is self._comm:
+                if not waited_comm:   # one stream-side wait covers every bucket enqueued so far
+                    w.wait()
+                    waited_comm = True
+            else:
+                w.wait()
             if not self._native_avg:
                 buf.div_(self.world)
         self._pending.clear()
+        for buf, dest in self._tied:   # reduced head gradient + reduced lookup gradient = the tied tensor's gradient
+            dest.add_(buf)
+        self._tied.clear()
 
 
 class Trainer:
@@ -107,6 +171,8 @@ class Trainer:
         self.model = model
         self.opt, self.sched = get_optim(model, lr, num_epochs, steps_per_epoch, warmup, max_grad_norm=max_grad_norm)
         self.reducer = GradReducer(model, group)
+        if hasattr(model, "defer_input_checks"):
+            model.defer_input_checks = True   # out-of-range ids / labels / masks raise at the end of training_step
         for holder in (model, getattr(model, "lora", None)):   # every replica draws its own dropout masks
             if hasattr(holder, "dropout_seed"):
                 holder.dropout_seed += 1000003 * self.reducer.rank
@@ -114,12 +180,15 @@ class Trainer:
     def training_step(self, batch):
         self.model.train()
         self.reducer.bucket_log.clear()
+        self.reducer.note_token_ids(batch.get("input_ids") if isinstance(batch, dict) else None)
         self.opt.zero_grad()
         loss = self.model(**batch).loss
         loss.backward()
         self.reducer.wait()
         self.opt.step()
         self.sched.step()
+        if hasattr(self.model, "raise_pending_errors"):
+            self.model.raise_pending_errors()   # (the optimizer step is queued behind backward by now)
         return loss.detach()
 
     @torch.no_grad()

@@ -18,15 +18,19 @@ def main(out_path):
                    num_attention_heads=2, num_key_value_heads=2, head_dim=128)
     m = MidiLM(cfg, device=torch.device("cuda", local), seed=0)
     red = GradReducer(m, min_bucket_elems=300_000)      # small buckets: several collectives per step
-    ids = torch.randint(3, cfg.vocab_size, (world, 256), generator=torch.Generator().manual_seed(4))
+    # ids below 400 of 1000: the embedding bucket is cut down to the rows some rank can have touched
+    ids = torch.randint(3, 400, (world, 256), generator=torch.Generator().manual_seed(4))
     mine = ids[rank:rank + 1].cuda()
     for _ in range(2):                                  # two steps: the buckets are re-used
         m.zero_grad()
+        red.bucket_log.clear()
+        red.note_token_ids(mine)
         loss = m(input_ids=mine, labels=mine).loss
         loss.backward()
         red.wait()
     if rank == 0:
-        torch.save({"grad": m.flat_grad.cpu(), "ids": ids}, out_path)
+        torch.save({"grad": m.flat_grad.cpu(), "ids": ids, "buckets": torch.tensor([b for b, _ in red.bucket_log])},
+                   out_path)
 
 
 if __name__ == "__main__":

@@ -69,3 +69,8 @@ def test_two_ranks_average_like_one_rank_on_the_whole_batch(tmp_path):
     want = m.flat_grad.cpu()
     err = float((got["grad"] - want).abs().max() / want.abs().max())
     assert err < 2e-2, err
+    # bucket order of a step: the tied head's weight gradient first (final at the start of backward, a buffer of its
+    # own), the layers, and last the embedding lookup's rows - only the rows [0, max id + 1) any rank can have touched
+    b = got["buckets"].tolist()
+    assert b[0] == cfg.vocab_size * cfg.hidden_size * 4
+    assert b[-1] == (int(got["ids"].max()) + 1) * cfg.hidden_size * 4 and b[-1] < b[0] // 2
