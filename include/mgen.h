@@ -310,6 +310,20 @@ int mgen_ce_fwd_bwd(void* logits, const long* labels, long tok0, long rows, int 
                     int is_bf16, mgen_stream_t stream);
 int mgen_ce_finalize(const float* row_loss, long T, const float* inv_count, float* loss, mgen_stream_t stream);
 
+/* lm_head + shifted cross entropy, forward and backward, with the chunk loop inside the library: per chunk of at most
+ * chunk_tokens rows, logits = x W^T -> cross entropy in place -> dx = dlogits W -> dW (+)= dlogits^T x (a plain store
+ * for the first 8192 rows of the call, accumulating launches after them). Replaces `logits = self.lm_head(hidden)` +
+ * `self.loss_function(...)` of Qwen3ForCausalLM.forward (TF models/qwen3/modeling_qwen3.py:495-499 ->
+ * TF loss/loss_utils.py:49-71) and autograd through both, as called from /root/reference/src/model/model.py:142-143.
+ * x [B*S][ldx] bf16, W [V][ldw] bf16, labels int64 [B][S]; loss fp32 scalar (device); with_grad: dx [B*S][lddx] bf16 and
+ * (unless null) dW [V][d] fp32, for an upstream gradient of 1. workspace: mgen_lmhead_ce_workspace_bytes(B*S, V,
+ * chunk_tokens) bytes, 256-byte aligned (one chunk of logits, the per-row losses, the label count). */
+long mgen_lmhead_ce_workspace_bytes(long T, int V, long chunk_tokens);
+int mgen_lmhead_ce_fwd_bwd(const void* x, long ldx, const void* W, long ldw, const long* labels, long B, int S, int V,
+                           int d, long ignore_index, long chunk_tokens, void* workspace, long workspace_bytes,
+                           float* loss, void* dx, long lddx, float* dW, int with_grad, int* err_flag,
+                           mgen_stream_t stream);
+
 /* ---- optimizer -----------------------------------------------------------------------------------------------
  * clip_grad_norm_ (reference src/train.py:66): out[0] = ||grad||_2, out[1] = min(1, max_norm/(norm+1e-6)).
  * workspace: mgen_sumsq_partial_count() doubles. */

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mgen_check_right_padding": [P, I, I, P, P],
     "mgen_ce_fwd_bwd": [P, P, L, L, I, L, I, L, P, F, P, P, I, I, P],
     "mgen_ce_finalize": [P, L, P, P, P],
+    "mgen_lmhead_ce_fwd_bwd": [P, L, P, L, P, L, I, I, I, L, L, P, L, P, P, L, P, I, P, P],
     "mgen_grad_norm_clip": [P, L, F, P, P, P],
     "mgen_grad_norm_clip_static": [P, L, F, P, P],
     "mgen_adamw_step": [P, P, P, P, P, L, P, F, F, F, F, F, L, P],
@@ -119,6 +120,8 @@ def lib():
         l.mgen_sumsq_partial_count.restype = ctypes.c_int
         l.mgen_gemm_slab_count.argtypes = [I, I]
         l.mgen_gemm_slab_count.restype = ctypes.c_int
+        l.mgen_lmhead_ce_workspace_bytes.argtypes = [L, I, L]
+        l.mgen_lmhead_ce_workspace_bytes.restype = ctypes.c_long
         l.mgen_gemm_skinny_fits.argtypes = [I, I, I, L, L, L, I]
         l.mgen_gemm_skinny_fits.restype = ctypes.c_int
         l.mgen_attn_decode_workspace.argtypes = [I, I, I, I]

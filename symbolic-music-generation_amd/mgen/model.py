@@ -678,6 +678,15 @@ class MidiLM(GenerationMixin, nn.Module):
         W = self._w(self._lm_head_name())
         ld = (V + 7) // 8 * 8
         chunk = min(cfg.lm_head_chunk_tokens, T)
+        if self.act_dtype == torch.bfloat16 and os.environ.get("MGEN_LMHEAD_C", "1") != "0":
+            # the chunk loop runs inside the library (mgen_lmhead_ce_fwd_bwd); the fp32 parity mode below keeps the
+            # same protocol written out with its three-product GEMMs
+            ws = ops.lmhead_ce_workspace(T, V, chunk, dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            dxN = torch.empty(T, d, dtype=torch.bfloat16, device=dev) if with_grad else None
+            ops.lmhead_ce_fwd_bwd(xN, W, labels, V, chunk, ws, loss, dxN,
+                                  grad_buf if (with_grad and self.lora is None) else None, self._err_flag)
+            return loss, dxN
         inv_count = torch.empty(1, dtype=torch.float32, device=dev)
         ops.ce_count(labels, inv_count, V=V, err_flag=self._err_flag)
         row_loss = torch.empty(T, dtype=torch.float32, device=dev)

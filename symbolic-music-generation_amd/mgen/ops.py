@@ -513,6 +513,22 @@ def ce_fwd_bwd(logits, labels, tok0, rows, V, ld, S, inv_count, grad_scale, row_
          _p(row_loss), _p(lse_out), int(write_grad), int(logits.dtype == torch.bfloat16), _stream())
 
 
+def lmhead_ce_workspace(T, V, chunk_tokens, device):
+    from ._lib import lib
+    n = lib().mgen_lmhead_ce_workspace_bytes(T, V, chunk_tokens)
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def lmhead_ce_fwd_bwd(x, w, labels, V, chunk_tokens, workspace, loss, dx, dw, err_flag=None, ignore_index=-100):
+    """Chunked lm_head + cross entropy (+ backward when dx is given; dw may be None for a frozen head), one call."""
+    _need_gpu(x, w, labels, workspace, loss, dx, dw)
+    B, S = labels.shape
+    d = x.shape[1]
+    call("mgen_lmhead_ce_fwd_bwd", _p(x), x.stride(0), _p(w), w.stride(0), _p(labels), B, S, V, d, ignore_index,
+         chunk_tokens, _p(workspace), workspace.numel(), _p(loss), _p(dx), dx.stride(0) if dx is not None else 0, _p(dw),
+         int(dx is not None), _p(err_flag), _stream())
+
+
 def ce_finalize(row_loss, inv_count, loss):
     call("mgen_ce_finalize", _p(row_loss), row_loss.numel(), _p(inv_count), _p(loss), _stream())
 

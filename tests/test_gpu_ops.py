@@ -534,3 +534,42 @@ def test_gemm_two_operand_pairs(ops, M, N, K, K2, tb):
     with pytest.raises(MgenError):   # reduction lengths must be multiples of 64
         ops.gemm_seg(A.to(dev()), b_st, A2.to(dev()), b2_st, c, M, N, K, 32, K, b_st.stride(0), K2, b2_st.stride(0),
                      ldc, tb, ops.OUT_BF16)
+
+
+# ----------------------------------------------------------------------------------------------- lm_head + CE in one call
+def test_lmhead_ce_entry_point_equals_the_written_out_protocol(ops):
+    """mgen_lmhead_ce_fwd_bwd (chunk loop inside the library) against the same protocol issued call by call: logits
+    GEMM, cross entropy in place, input gradient, weight gradient (store, then accumulate); ragged last chunk, ignored
+    labels, V not a multiple of 8; and against fp32 autograd."""
+    from mgen._lib import MgenError
+    B, S, V, d, chunk = 3, 50, 1031, 256, 64
+    T = B * S
+    g = torch.Generator().manual_seed(12)
+    x = bf(torch.randn(T, d, generator=g)).to(dev())
+    w = bf(torch.randn(V, d, generator=g) * 0.05).to(dev())
+    labels = torch.randint(0, V, (B, S), generator=g)
+    labels[0, :7] = -100
+    labels = labels.to(dev())
+    ws = ops.lmhead_ce_workspace(T, V, chunk, dev())
+    loss = torch.empty((), device=dev())
+    dx = torch.empty(T, d, dtype=torch.bfloat16, device=dev())
+    dw = torch.full((V, d), 7.0, device=dev())          # overwritten, not added to
+    ops.lmhead_ce_fwd_bwd(x, w, labels, V, chunk, ws, loss, dx, dw)
+    # fp32 autograd on the same bf16 inputs (logits rounded to bf16 as the kernel stores them)
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    logits = (xr @ wr.t()).to(torch.bfloat16).float() + 0 * (xr @ wr.t())
+    lab = torch.nn.functional.pad(labels, (0, 1), value=-100)[:, 1:].reshape(-1)
+    ref = torch.nn.functional.cross_entropy((xr @ wr.t()), lab, ignore_index=-100)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 2e-3 * float(ref)
+    assert rel(dx.float(), xr.grad) < 2e-2 and rel(dw, wr.grad) < 2e-2
+    # forward only
+    loss2 = torch.empty((), device=dev())
+    ops.lmhead_ce_fwd_bwd(x, w, labels, V, chunk, ws, loss2, None, None)
+    assert torch.equal(loss, loss2)
+    # frozen head: dx without dW
+    dx3 = torch.empty_like(dx)
+    ops.lmhead_ce_fwd_bwd(x, w, labels, V, chunk, ws, loss2, dx3, None)
+    assert torch.equal(dx, dx3)
+    with pytest.raises(MgenError):
+        ops.lmhead_ce_fwd_bwd(x, w, labels, V, chunk, ws[:1024], loss2, None, None)
