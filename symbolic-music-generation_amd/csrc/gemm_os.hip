@@ -517,7 +517,10 @@ bool mgen_gemm_os_fits(int M, int N, int K, long lda, long ldb, long ldc, long l
     }
     // the products with few output columns: whole 256-row tiles (rows beyond the operand would be read), at least as
     // many tiles as CUs
-    if (M % 256 != 0 || N % 256 != 0 || N > 1024 || (long)(M / 256) * (N / 256) < 256) return false;
+    // (input gradients up to MGEN_GEMM_OS_NMAX output columns, default 2048: the column tiles of a row panel are
+    // neighbours in the XCD-aware order and share the panel's rows in L2)
+    static const int nmax = [] { const char* v = getenv("MGEN_GEMM_OS_NMAX"); return v ? atoi(v) : 2048; }();
+    if (M % 256 != 0 || N % 256 != 0 || N > (dgrad ? nmax : 1024) || (long)(M / 256) * (N / 256) < 256) return false;
     if ((ldc % 8) || (proj && ((ldc % 4) || (ldr % 4)))) return false;
     if (256L * lda * 2 >= (1L << 32)) return false;
     if (dgrad ? (long)K * ldb * 2 >= (1L << 32) : 256L * ldb * 2 >= (1L << 32)) return false;

@@ -213,7 +213,8 @@ void launch_rmsnorm_bwd(hipStream_t stream, int slot, const void* dy, const floa
                         const float* rstd, float* dres, void* dres_lp, float* dw, long T, int d, int accumulate) {
     constexpr int NW = VPL <= 2 ? 16 : 4;
     const long b = (T + NW - 1) / NW;
-    const long cap = VPL <= 2 ? 256 : 512;   // one 16-wave block per CU / two 4-wave blocks
+    // one 16-wave block per CU / three 4-wave blocks (rows of up to 1536: 3 waves per SIMD fit) / two 4-wave blocks
+    const long cap = VPL <= 2 ? 256 : (VPL <= 6 ? 768 : 512);
     const dim3 grid((int)(b < cap ? b : cap));
     const dim3 block(64 * NW);
     if (slot >= 0)
@@ -258,6 +259,9 @@ extern "C" int mgen_rmsnorm_bwd(const void* dy, const float* x, const float* w, 
     if (d <= 512) {
         if (dy_bf16) launch_rmsnorm_bwd<2, bf16>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
         else launch_rmsnorm_bwd<2, float>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
+    } else if (d <= 1536) {
+        if (dy_bf16) launch_rmsnorm_bwd<6, bf16>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
+        else launch_rmsnorm_bwd<6, float>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
     } else {
         if (dy_bf16) launch_rmsnorm_bwd<8, bf16>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);
         else launch_rmsnorm_bwd<8, float>(stream, slot, dy, x, w, rstd, dres, dres_lp, dw, T, d, accumulate);

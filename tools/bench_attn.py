@@ -10,8 +10,11 @@ B, S, H, D = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (32, 204
 dev = torch.device("cuda:0")
 T = B * S
 bf = torch.bfloat16
-q = torch.randn(T, H * D, device=dev).to(bf); k = torch.randn(T, H * D, device=dev).to(bf)
-v = torch.randn(T, H * D, device=dev).to(bf); do = torch.randn(T, H * D, device=dev).to(bf)
+# DATA_SCALE=0: all-zero operands (same instruction stream, least switching power: separates what the clock under
+# load costs from what instruction issue costs)
+_sc = float(os.environ.get("DATA_SCALE", "1"))
+q = (torch.randn(T, H * D, device=dev) * _sc).to(bf); k = (torch.randn(T, H * D, device=dev) * _sc).to(bf)
+v = (torch.randn(T, H * D, device=dev) * _sc).to(bf); do = (torch.randn(T, H * D, device=dev) * _sc).to(bf)
 o = torch.empty(T, H * D, dtype=bf, device=dev); lse = torch.empty(B, H, S, device=dev)
 dq = torch.empty_like(q); dk = torch.empty_like(q); dv = torch.empty_like(q); delta = torch.empty(B, H, S, device=dev)
 HD = H * D
