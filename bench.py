@@ -65,14 +65,24 @@ def cpu_baseline(cfg, S, seconds_budget=25.0):
                       f"best of {len(times)} runs, {best:.2f} s/step"}
 
 
-def pmc_decode_traffic(streams, prompt_len):
-    """HBM bytes per decode step from the committed counter passes (profiles/r02_pmc_traffic.json, section "decode":
-    256 streams, contexts 1792..1808): every kernel of a decode step, fetch + write. None for any other shape."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if (streams, prompt_len) != (256, 1792) or not os.path.exists(path):
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_DECODE_CONTEXTS = os.path.join(ROOT, "profiles", "r03_pmc_decode_contexts.json")
+
+
+def pmc_decode_traffic(streams, prompt_len, new_tokens):
+    """HBM bytes per decode step (every kernel of a step, fetch + write) from the committed counter passes. For 256
+    streams at contexts 1792.. : the "decode" section of profiles/r03_pmc_traffic.json. For the literal run (one-token
+    prompt to 4096 tokens): the run average from the line through the passes at three contexts
+    (profiles/r03_pmc_decode_contexts.json; bytes per step are linear in the context). None for any other shape."""
+    if streams != 256:
         return None
-    with open(path) as fh:
-        return json.load(fh).get("decode_step_hbm_bytes")
+    if prompt_len == 1792 and os.path.exists(PMC_TRAFFIC):
+        with open(PMC_TRAFFIC) as fh:
+            return json.load(fh).get("decode_step_hbm_bytes")
+    if prompt_len == 1 and new_tokens == 4095 and os.path.exists(PMC_DECODE_CONTEXTS):
+        with open(PMC_DECODE_CONTEXTS) as fh:
+            return json.load(fh).get("decode_literal_run_avg_step_hbm_bytes")
+    return None
 
 
 def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
@@ -110,9 +120,10 @@ def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": round(gbs / PEAK_HBM_GBS, 4),
                          "algorithmic_bytes": round(bytes_total / steps),
-                         "traffic": pmc_decode_traffic(streams, prompt_len),
+                         "traffic": pmc_decode_traffic(streams, prompt_len, new_tokens),
                          "traffic_unit": "HBM bytes per decode step, all kernels of the step (PMC FETCH_SIZE + WRITE_SIZE, "
-                                         "profiles/r02_pmc_traffic.json); algorithmic_bytes = run average per step"},
+                                         "profiles/r03_pmc_traffic.json, r03_pmc_decode_contexts.json); "
+                                         "algorithmic_bytes = run average per step"},
             "sampling": "T=0.97 top_p=0.95 top_k=off philox(seed 1234)", "out_shape": list(out.shape)}
 
 
@@ -254,10 +265,10 @@ def main():
     ms = sum(r[1].elapsed_time(r[2]) for r in recs)
     achieved = fl / (ms * 1e-3) / 1e12
     # HBM traffic per launch of this kernel cannot be counted from inside the process: it comes from the committed
-    # PMC passes of this same command (profiles/r02_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs,
+    # PMC passes of this same command (profiles/r03_pmc_traffic.json: separate FETCH_SIZE and WRITE_SIZE runs,
     # FETCH doubled per the gfx950 note), valid for the default workload only
     traffic = None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+    pmc = PMC_TRAFFIC
     if (B, S) == (32, 2048) and args.model == "default" and os.path.exists(pmc):
         with open(pmc) as fh:
             traffic = json.load(fh).get("roofline_kernel_avg_bytes_per_launch")
@@ -268,7 +279,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": kname,
                 "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC, profiles/r02_pmc_traffic.json); algorithmic: "
+                "traffic_unit": "HBM bytes per launch (PMC, profiles/r03_pmc_traffic.json); algorithmic: "
                                 "2*(M*K + N*K + M*N) bytes",
                 "algorithmic_bytes_per_launch": round(sum(r[3] for r in recs) / len(recs)),
                 "launches": len(recs), "avg_launch_ms": round(ms / len(recs), 4),

@@ -57,6 +57,8 @@ class LMConfig:
     tie_word_embeddings: bool = True
     qk_norm: bool = True          # Qwen3: per-head RMSNorm on q and k; Llama: none
     rope_interleaved: bool = False  # rotation pairs (2i, 2i+1) instead of the split-half pairs (i, i + Dh/2)
+    norm_kind: str = "rms"        # "layer": nn.LayerNorm (gain + bias, eps = layer_norm_eps) in place of every RMSNorm
+    layer_norm_eps: float = 1e-5
     bos_token_id: int = 1
     eos_token_id: int = 2
     pad_token_id: int = 0
@@ -76,6 +78,9 @@ def init_params(cfg: LMConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
     for l in range(cfg.num_hidden_layers):
         pre = f"model.layers.{l}."
         p[pre + "input_layernorm.weight"] = torch.ones(d)
+        if cfg.norm_kind == "layer":
+            p[pre + "input_layernorm.bias"] = torch.zeros(d)
+            p[pre + "post_attention_layernorm.bias"] = torch.zeros(d)
         p[pre + "self_attn.q_proj.weight"] = lin(H * Dh, d)
         p[pre + "self_attn.k_proj.weight"] = lin(KVH * Dh, d)
         p[pre + "self_attn.v_proj.weight"] = lin(KVH * Dh, d)
@@ -88,6 +93,8 @@ def init_params(cfg: LMConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
         p[pre + "mlp.up_proj.weight"] = lin(I, d)
         p[pre + "mlp.down_proj.weight"] = lin(d, I)
     p["model.norm.weight"] = torch.ones(d)
+    if cfg.norm_kind == "layer":
+        p["model.norm.bias"] = torch.zeros(d)
     if not cfg.tie_word_embeddings:
         p["lm_head.weight"] = lin(cfg.vocab_size, d)
     return p
@@ -102,6 +109,15 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     var = xf.pow(2).mean(-1, keepdim=True)
     xf = xf * torch.rsqrt(var + eps)
     return w * xf.to(in_dtype)
+
+
+def block_norm(h: torch.Tensor, p: Dict[str, torch.Tensor], name: str, cfg: "LMConfig") -> torch.Tensor:
+    """The decoder block's norm `name` (.weight / .bias in p): RMSNorm, or torch.nn.LayerNorm evaluated in fp32 (what
+    autocast does to layer_norm; the residual stream is fp32 in both precisions)."""
+    if cfg.norm_kind == "layer":
+        return F.layer_norm(h.to(torch.float32), (h.shape[-1],), p[name + ".weight"], p[name + ".bias"],
+                            cfg.layer_norm_eps)
+    return rmsnorm(h, p[name + ".weight"], cfg.rms_norm_eps)
 
 
 def rope_inv_freq(head_dim: int, theta: float) -> torch.Tensor:
@@ -195,7 +211,7 @@ def decoder_layer(h: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, cfg: LM
                   taps: Optional[dict] = None) -> torch.Tensor:
     B, S, d = h.shape
     H, KVH, Dh = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-    x = rmsnorm(h, p[pre + "input_layernorm.weight"], cfg.rms_norm_eps)
+    x = block_norm(h, p, pre + "input_layernorm", cfg)
     q = linear(x, p[pre + "self_attn.q_proj.weight"], mode).view(B, S, H, Dh)
     k = linear(x, p[pre + "self_attn.k_proj.weight"], mode).view(B, S, KVH, Dh)
     v = linear(x, p[pre + "self_attn.v_proj.weight"], mode).view(B, S, KVH, Dh)
@@ -223,7 +239,7 @@ def decoder_layer(h: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, cfg: LM
     if taps is not None and layer == 0:
         taps["q_rot0"], taps["k_rot0"], taps["attn0"] = q, k, a
     h = h + linear(a, p[pre + "self_attn.o_proj.weight"], mode)
-    x = rmsnorm(h, p[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+    x = block_norm(h, p, pre + "post_attention_layernorm", cfg)
     g = linear(x, p[pre + "mlp.gate_proj.weight"], mode)
     u = linear(x, p[pre + "mlp.up_proj.weight"], mode)
     h = h + linear(F.silu(g) * u, p[pre + "mlp.down_proj.weight"], mode)
@@ -248,7 +264,7 @@ def forward_hidden(p: Dict[str, torch.Tensor], cfg: LMConfig, input_ids: torch.T
         h = decoder_layer(h, p, f"model.layers.{l}.", cfg, cos, sin, mode, kpm, cache, l, taps)
         if taps is not None and l == 0:
             taps["h_after0"] = h
-    return rmsnorm(h, p["model.norm.weight"], cfg.rms_norm_eps)
+    return block_norm(h, p, "model.norm", cfg)
 
 
 def lm_head_weight(p: Dict[str, torch.Tensor], cfg: LMConfig) -> torch.Tensor:

@@ -22,6 +22,10 @@ class LMConfig:
     tie_word_embeddings: bool = True
     qk_norm: bool = True           # Qwen3 blocks normalise q and k per head; Llama blocks do not
     rope_interleaved: bool = False  # rotation pairs (2i, 2i+1) instead of (i, i + head_dim/2) (token models)
+    # "rms": RMSNorm blocks (Qwen3 / Llama). "layer": LayerNorm with gain and bias (eps = layer_norm_eps) in the same
+    # pre-norm block - the other half of the Aria block variant (LayerNorm + adjacent-pair RoPE + fused QKV + SwiGLU;
+    # module names in /root/reference/src/model/model.py:239,263-269)
+    norm_kind: str = "rms"
     bos_token_id: int = 1
     eos_token_id: int = 2
     pad_token_id: int = 0
@@ -72,8 +76,13 @@ def gpt2_decoder(vocab_size: int = 30000, n_positions: int = 4096, pdrop: float 
                     tie_word_embeddings=True, qk_norm=False, embd_pdrop=pdrop, resid_pdrop=pdrop, attn_pdrop=pdrop)
 
 
-def aria_style_llama() -> LMConfig:
-    """~650M Llama-architecture stand-in for the remote-code Aria model used by src/train_aria.py."""
-    return LMConfig(vocab_size=17727, hidden_size=1536, intermediate_size=6144, num_hidden_layers=16,
-                    num_attention_heads=24, num_key_value_heads=24, head_dim=64, max_position_embeddings=8192,
-                    rms_norm_eps=1e-6, rope_theta=10000.0, tie_word_embeddings=False, qk_norm=False)
+def aria_style_llama(aria_block: bool = False) -> LMConfig:
+    """~650M Llama-architecture stand-in for the remote-code Aria model used by src/train_aria.py (the benchmark
+    configurations' model: RMSNorm, split-half RoPE). aria_block=True: the block as the checkpoint's own code is
+    recalled to have it - LayerNorm with gain and bias, adjacent-pair RoPE - unverifiable offline either way."""
+    cfg = LMConfig(vocab_size=17727, hidden_size=1536, intermediate_size=6144, num_hidden_layers=16,
+                   num_attention_heads=24, num_key_value_heads=24, head_dim=64, max_position_embeddings=8192,
+                   rms_norm_eps=1e-6, rope_theta=10000.0, tie_word_embeddings=False, qk_norm=False)
+    if aria_block:
+        cfg.norm_kind, cfg.rope_interleaved = "layer", True
+    return cfg

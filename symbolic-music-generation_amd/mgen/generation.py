@@ -107,7 +107,7 @@ class GenerationMixin:
     def _decode_begin(self, tokens, buf: _DecodeBuffers):
         """Start of a one-token step: embedding row per stream and the first layer's input norm."""
         ops.embedding_fwd(tokens, self.model.embed_tokens.weight, buf.h0, self._err_flag)
-        ops.rmsnorm_fwd(buf.h0, self._layers[0].w_ln1, buf.x, None, self.cfg.rms_norm_eps)
+        self._norm_fwd(buf.h0, self._layers[0].w_ln1, self._layers[0].w_ln1b, buf.x, want_stats=False)
         buf.h = buf.h0
 
     def _decode_layer(self, l: int, cache, t: int, buf: _DecodeBuffers, lens, ws):
@@ -138,7 +138,7 @@ class GenerationMixin:
             ops.linear_skinny(buf.att, v.s_o, buf.slabs, slabs=True)
         else:
             ops.linear_slabs(buf.att, v.s_o, buf.slabs, buf.ns_o)
-        ops.slab_resid_rmsnorm(buf.slabs, buf.ns_o, h, buf.h1, v.w_ln2, buf.x, eps)
+        self._slab_resid_norm(buf.slabs, buf.ns_o, h, buf.h1, v.w_ln2, v.w_ln2b, buf.x)
         if buf.sk_gu:
             ops.linear_skinny(buf.x, v.s_gu, buf.gu)
         else:
@@ -150,8 +150,17 @@ class GenerationMixin:
             ops.linear_slabs(buf.act, v.s_down, buf.slabs, buf.ns_d)
         nxt = buf.h2 if h is buf.h0 else buf.h0
         w_next = self._layers[l + 1].w_ln1 if l + 1 < L else self.model.norm.weight
-        ops.slab_resid_rmsnorm(buf.slabs, buf.ns_d, buf.h1, nxt, w_next, buf.x, eps)
+        b_next = self._layers[l + 1].w_ln1b if l + 1 < L else self._final_norm_bias()
+        self._slab_resid_norm(buf.slabs, buf.ns_d, buf.h1, nxt, w_next, b_next, buf.x)
         buf.h = nxt
+
+    def _slab_resid_norm(self, slabs, ns, resid, h_out, w, b, y):
+        """h_out = resid + bf16(sum of the projection's slabs); y = the following norm of h_out."""
+        if self._ln:   # LayerNorm blocks: the slab sum + residual in one launch, the norm in the next
+            ops.slab_resid_rmsnorm(slabs, ns, resid, h_out, None, None, self._norm_eps)
+            self._norm_fwd(h_out, w, b, y)
+        else:
+            ops.slab_resid_rmsnorm(slabs, ns, resid, h_out, w, y, self._norm_eps)
 
     def _decode_end(self, buf: _DecodeBuffers):
         """lm_head on the final-normed rows; returns bf16 logits [B, ldv]."""

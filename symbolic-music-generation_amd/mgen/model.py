@@ -59,6 +59,8 @@ def param_layout(cfg: LMConfig) -> List[Tuple[str, Tuple[int, ...]]]:
     for l in range(cfg.num_hidden_layers):
         p = f"model.layers.{l}."
         out.append((p + "input_layernorm.weight", (d,)))
+        if cfg.norm_kind == "layer":
+            out.append((p + "input_layernorm.bias", (d,)))
         out.append((p + "self_attn.q_proj.weight", (H * Dh, d)))     # q, k, v adjacent = one [qkv_width, d] matrix
         out.append((p + "self_attn.k_proj.weight", (KVH * Dh, d)))
         out.append((p + "self_attn.v_proj.weight", (KVH * Dh, d)))
@@ -67,10 +69,14 @@ def param_layout(cfg: LMConfig) -> List[Tuple[str, Tuple[int, ...]]]:
             out.append((p + "self_attn.k_norm.weight", (Dh,)))
         out.append((p + "self_attn.o_proj.weight", (d, H * Dh)))
         out.append((p + "post_attention_layernorm.weight", (d,)))
+        if cfg.norm_kind == "layer":
+            out.append((p + "post_attention_layernorm.bias", (d,)))
         out.append((p + "mlp.gate_proj.weight", (I, d)))             # gate, up adjacent = one [2I, d] matrix
         out.append((p + "mlp.up_proj.weight", (I, d)))
         out.append((p + "mlp.down_proj.weight", (d, I)))
     out.append(("model.norm.weight", (d,)))
+    if cfg.norm_kind == "layer":
+        out.append(("model.norm.bias", (d,)))
     if cfg.pos4d:
         out.append(("lm_head.weight", (POS4D_HEAD_OUT, d)))
     elif not cfg.tie_word_embeddings:
@@ -120,6 +126,12 @@ class MidiLM(GenerationMixin, nn.Module):
         self.device_ = torch.device(device)
         d = cfg.hidden_size
         assert cfg.head_dim in (64, 128) and d % 8 == 0 and cfg.intermediate_size % 8 == 0
+        if cfg.norm_kind not in ("rms", "layer"):
+            raise ValueError("norm_kind is 'rms' or 'layer'")
+        if cfg.norm_kind == "layer" and cfg.pos4d:
+            raise ValueError("the 4-D position model has RMSNorm blocks")
+        self._ln = cfg.norm_kind == "layer"
+        self._norm_eps = cfg.layer_norm_eps if self._ln else cfg.rms_norm_eps
         layout = self._param_layout()
         offs, off = {}, 0
         for name, shape in layout:
@@ -305,6 +317,8 @@ class MidiLM(GenerationMixin, nn.Module):
             view = (lambda name, shape=None: self._w(name, shape)) if flat is None else \
                 (lambda name, shape=None, flat=flat: self._view(flat, name, shape))
             setattr(v, tag + "_ln1", view(p + "input_layernorm.weight"))
+            setattr(v, tag + "_ln1b", view(p + "input_layernorm.bias") if cfg.norm_kind == "layer" else None)
+            setattr(v, tag + "_ln2b", view(p + "post_attention_layernorm.bias") if cfg.norm_kind == "layer" else None)
             setattr(v, tag + "_qkv", view(p + "self_attn.q_proj.weight", (cfg.qkv_width, d)))
             setattr(v, tag + "_o", view(p + "self_attn.o_proj.weight"))
             setattr(v, tag + "_ln2", view(p + "post_attention_layernorm.weight"))
@@ -330,11 +344,37 @@ class MidiLM(GenerationMixin, nn.Module):
         g = torch.Generator(device=self.flat_param.device).manual_seed(seed)
         with torch.no_grad():
             for name, prm in self.named_parameters():
-                if "norm" in name:
+                if name.endswith(".bias"):
+                    prm.zero_()
+                elif "norm" in name:
                     prm.fill_(1.0)
                 else:
                     prm.normal_(0.0, 0.02, generator=g)
         self._shadow_version = -1
+
+    # the block's norm: RMSNorm (gain) or LayerNorm (gain + bias); `stats` = rstd, or (mean, rstd)
+    def _norm_fwd(self, h, w, b, y, want_stats=True):
+        T = h.shape[0]
+        dev = h.device
+        if self._ln:
+            mean = torch.empty(T, dtype=torch.float32, device=dev)
+            rstd = torch.empty(T, dtype=torch.float32, device=dev)
+            ops.layernorm_fwd(h, w, b, y, mean, rstd, self._norm_eps)
+            return (mean, rstd)
+        rstd = torch.empty(T, dtype=torch.float32, device=dev) if want_stats else None
+        ops.rmsnorm_fwd(h, w, y, rstd, self._norm_eps)
+        return rstd
+
+    def _norm_bwd(self, dy, x, w, stats, dres, dres_lp, gw, gb, accumulate):
+        if self._ln:
+            ops.layernorm_bwd(dy, x, w, stats[0], stats[1], dres, dres_lp, gw, gb, accumulate)
+        else:
+            ops.rmsnorm_bwd(dy, x, w, stats, dres, dres_lp, gw, accumulate)
+
+    def _final_norm_bias(self, flat=None):
+        if not self._ln:
+            return None
+        return self.model.norm.bias if flat is None else self._view(flat, "model.norm.bias")
 
     def _lm_head_name(self):
         return "model.embed_tokens.weight" if self.cfg.tie_word_embeddings else "lm_head.weight"
@@ -598,8 +638,7 @@ class MidiLM(GenerationMixin, nn.Module):
             la = lo.layers[l] if lo is not None else None
             lk = lkeys[l] if lkeys is not None else (None,) * 5   # adapter dropout keys: qkv, o, gate, up, down
             x1 = torch.empty(T, d, dtype=bf, device=dev)
-            rstd1 = torch.empty(T, dtype=torch.float32, device=dev)
-            ops.rmsnorm_fwd(h, v.w_ln1, x1, rstd1, cfg.rms_norm_eps)
+            rstd1 = self._norm_fwd(h, v.w_ln1, v.w_ln1b, x1)
             # (training without adapters: 128 bytes of row padding, so that the 6 KiB pitch of the rows the QKV product
             # stores by column segments is not a multiple of 2 KiB - 210 -> 179 us for that product)
             qpad = _ROW_PAD if (save is not None and lo is None and not f32 and not cfg.pos4d and cache is None
@@ -641,8 +680,7 @@ class MidiLM(GenerationMixin, nn.Module):
             else:
                 ops.linear_fwd(att_o, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
             x2 = torch.empty(T, d, dtype=bf, device=dev)
-            rstd2 = torch.empty(T, dtype=torch.float32, device=dev)
-            ops.rmsnorm_fwd(h_mid, v.w_ln2, x2, rstd2, cfg.rms_norm_eps)
+            rstd2 = self._norm_fwd(h_mid, v.w_ln2, v.w_ln2b, x2)
             gu = torch.empty(T, 2 * I, dtype=bf, device=dev)
             act = torch.empty(T, I, dtype=bf, device=dev)   # (row padding measured here too: 0.3-0.8 ms slower)
             if fused:   # t = [t_gate | t_up], then one product with the block-diagonal [B_gate, B_up] behind [Wg; Wu]
@@ -662,8 +700,7 @@ class MidiLM(GenerationMixin, nn.Module):
                              (t_qkv, t_o, t_gu, t_down, lk) if la is not None else None))
             h = h_out
         xN = torch.empty(T, d, dtype=bf, device=dev)
-        rstdN = torch.empty(T, dtype=torch.float32, device=dev)
-        ops.rmsnorm_fwd(h, self.model.norm.weight, xN, rstdN, cfg.rms_norm_eps)
+        rstdN = self._norm_fwd(h, self.model.norm.weight, self._final_norm_bias(), xN)
         return xN, (h, rstdN, cs)
 
     def _lm_head_loss(self, xN, labels, with_grad: bool, grad_buf=None):
@@ -749,7 +786,8 @@ class MidiLM(GenerationMixin, nn.Module):
         group = lo is None and not f32
         dh_lp_att = torch.empty(T, d, dtype=bf, device=dev) if group else dh_lp
         g_norm = self._view(self.flat_grad, "model.norm.weight")
-        ops.rmsnorm_bwd(dxN, h_last, self.model.norm.weight, rstdN, dh, dh_lp, g_norm, accumulate=False)
+        self._norm_bwd(dxN, h_last, self.model.norm.weight, rstdN, dh, dh_lp, g_norm,
+                       self._final_norm_bias(self.flat_grad), accumulate=False)
         if grad_hook is not None:
             grad_hook("head")
         # Gradient activations that the GEMM kernels read or write by column segments of many rows at a time get 64
@@ -799,7 +837,7 @@ class MidiLM(GenerationMixin, nn.Module):
                        key=lts[4][3])
             dh_mlp = dh_lp            # what the MLP branch's weight gradients were taken from
             dh_lp = dh_lp_att         # (the same buffer unless the weight gradients are grouped)
-            ops.rmsnorm_bwd(dx, h_mid, v.w_ln2, rstd2, dh, dh_lp, v.g_ln2, accumulate=True)
+            self._norm_bwd(dx, h_mid, v.w_ln2, rstd2, dh, dh_lp, v.g_ln2, v.g_ln2b, accumulate=True)
             # ---- attention branch
             if fused:
                 lo.bwd_fused(dh_lp, att_o, lts[1], v.s_o, la, "o", datt, H * Dh, d)
@@ -842,7 +880,7 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.linear_wgrad_group([(dh_mlp, act, v.g_down), (dgu, x2, v.g_gu), (dh_lp, att_o, v.g_o),
                                         (dqkv, x1, v.g_qkv)])
             dh_lp = dh_mlp            # the next layer's MLP branch reads (and keeps) this one
-            ops.rmsnorm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, accumulate=True)
+            self._norm_bwd(dx, h_in, v.w_ln1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1, v.g_ln1b, accumulate=True)
             saved[l] = None
             if grad_hook is not None:
                 grad_hook(l)

@@ -19,7 +19,19 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -
 cd $R
 python3 tools/pmc_traffic.py $OUT/pmc_traffic.json \
   train=$OUT/train_fetch/t_counter_collection.csv,$OUT/train_write/t_counter_collection.csv,$OUT/train_trace/t_kernel_trace.csv \
-  decode=$OUT/dec_fetch/t_counter_collection.csv,$OUT/dec_write/t_counter_collection.csv,$OUT/dec_trace/t_kernel_trace.csv
+  decode=$OUT/dec_fetch/t_counter_collection.csv,$OUT/dec_write/t_counter_collection.csv,$OUT/dec_trace/t_kernel_trace.csv \
+  decode_streams=256
+# decode traffic at three more contexts (9 steps each): the line through them gives the literal run's average
+SPECS=""
+for CTX in 256 2048 3840; do
+  D2="$R/tools/profile_decode.py run 256 $CTX 9"
+  timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/d${CTX}_trace -o t -- python3 $D2 > $OUT/d_trace.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/d${CTX}_fetch -o t -- python3 $D2 > $OUT/d_fetch.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/d${CTX}_write -o t -- python3 $D2 > $OUT/d_write.log 2>&1
+  SPECS="$SPECS decode@$CTX=$OUT/d${CTX}_fetch/t_counter_collection.csv,$OUT/d${CTX}_write/t_counter_collection.csv,$OUT/d${CTX}_trace/t_kernel_trace.csv"
+done
+python3 tools/pmc_traffic.py $OUT/pmc_decode_contexts.json decode_streams=256 $SPECS
+rm -rf $OUT/d*_trace $OUT/d*_fetch $OUT/d*_write
 python3 tools/pmc_sum.py $OUT/train_mfma attn_ > $OUT/attn_mfma_busy.txt
 python3 tools/profile_decode.py report $OUT/dec_trace/t_kernel_trace.csv > $OUT/decode_steps_only.txt
 cp $OUT/train_trace/t_kernel_stats.csv $OUT/train_step_kernel_stats.csv

@@ -93,12 +93,40 @@ def main(out, specs):
     doc = {"units": "bytes per launch; FETCH_SIZE (KiB) x 1024 x 2 (gfx950: 16 B/lane streaming reads are tallied at half), "
                     "WRITE_SIZE (KiB) x 1024; avg_us from a --kernel-trace pass of the same command; GBps = (fetch + write) / avg_us",
            "passes": "separate rocprofv3 runs per counter (--pmc FETCH_SIZE, --pmc WRITE_SIZE) and for the kernel trace"}
+    streams = None
     for spec in specs:
+        if spec.startswith("decode_streams="):   # streams of the decode run: a batch may be decoded in several parts
+            streams = int(spec.split("=")[1])
+    for spec in specs:
+        if spec.startswith("decode_streams="):
+            continue
         label, files = spec.split("=")
         doc[label] = section(*files.split(","), decode=label.startswith("decode"))
         if label.startswith("decode"):
-            doc[label + "_step_hbm_bytes"] = round(sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches_per_decode_step"]
-                                                       for r in doc[label] if "launches_per_decode_step" in r))
+            part_bytes = sum((r["fetch_bytes"] + r["write_bytes"]) * r["launches_per_decode_step"]
+                             for r in doc[label] if "launches_per_decode_step" in r)
+            # a "step" above runs from one token-embedding launch to the next, i.e. over ONE part of the batch; the
+            # embedding kernel takes 4 rows per workgroup, which tells how many streams a part holds
+            parts = 1
+            emb = [r for r in doc[label] if r["kernel"].startswith("embedding_fwd") and "launches_per_decode_step" in r]
+            if streams and emb:
+                parts = max(1, round(streams / (4 * emb[0]["workgroups"])))
+            doc[label + "_parts"] = parts
+            doc[label + "_step_hbm_bytes"] = round(part_bytes * parts)
+    # Sections named decode@<context>: HBM bytes per step are linear in the context (weights + logits + KV rows read),
+    # so a least-squares line through them gives the run average of a decode run over contexts 1 .. 4095 (the
+    # literal 256-stream x 4096-token benchmark run) at its mean context, 2048.
+    # (a section decode@P is a run from a P-token prompt over 8 decode steps: contexts P + 1 .. P + 8, mean P + 4.5)
+    pts = [(int(k.split("@")[1].split("_")[0]) + 4.5, v) for k, v in doc.items()
+           if k.startswith("decode@") and k.endswith("_step_hbm_bytes")]
+    if len(pts) >= 2:
+        n = len(pts)
+        mx, my = sum(p[0] for p in pts) / n, sum(p[1] for p in pts) / n
+        b = sum((p[0] - mx) * (p[1] - my) for p in pts) / sum((p[0] - mx) ** 2 for p in pts)
+        a = my - b * mx
+        doc["decode_bytes_per_step_fit"] = {"constant": round(a), "per_context_token": round(b, 1),
+                                            "points": sorted(pts)}
+        doc["decode_literal_run_avg_step_hbm_bytes"] = round(a + b * 2048.0)
     # the kernel bench.py's roofline block times: the plain instance of the register-panel GEMM (K = 512 products: QKV,
     # lm_head logits, o_proj / down_proj input gradients)
     fwd = [r for r in doc.get("train", []) if r["kernel"].startswith("gemm_rs_kernel<false")]

@@ -59,6 +59,8 @@ def report(path):
             two += ts - prev
         depth += dlt
         prev = ts
+    print("(a step here runs from one token-embedding launch to the next: ONE part of the batch when the batch is "
+          "decoded in parts; the whole batch advances one token per `parts` such steps)")
     print(f"decode steps {steps}; wall {span / steps / 1e3:.1f} us/step; kernel time {busy / steps / 1e3:.1f} us/step; "
           f"some kernel running {one / steps / 1e3:.1f} us/step (idle {(span - one) / steps / 1e3:.1f}); "
           f">= 2 kernels running {two / steps / 1e3:.1f} us/step")
