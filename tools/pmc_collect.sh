@@ -31,7 +31,7 @@ for CTX in 256 2048 3840; do
   SPECS="$SPECS decode@$CTX=$OUT/d${CTX}_fetch/t_counter_collection.csv,$OUT/d${CTX}_write/t_counter_collection.csv,$OUT/d${CTX}_trace/t_kernel_trace.csv"
 done
 python3 tools/pmc_traffic.py $OUT/pmc_decode_contexts.json decode_streams=256 $SPECS
-rm -rf $OUT/d*_trace $OUT/d*_fetch $OUT/d*_write
+rm -rf $OUT/d[0-9]*_trace $OUT/d[0-9]*_fetch $OUT/d[0-9]*_write
 python3 tools/pmc_sum.py $OUT/train_mfma attn_ > $OUT/attn_mfma_busy.txt
 python3 tools/profile_decode.py report $OUT/dec_trace/t_kernel_trace.csv > $OUT/decode_steps_only.txt
 cp $OUT/train_trace/t_kernel_stats.csv $OUT/train_step_kernel_stats.csv
