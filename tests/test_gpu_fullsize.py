@@ -16,9 +16,11 @@ def test_aria_size_model_trains_at_seq_4096():
     m = MidiLM(cfg, device="cuda:0", seed=0)
     assert sum(p.numel() for p in m.parameters()) == 658_487_808
     g = torch.Generator().manual_seed(5)
-    ids = torch.randint(3, cfg.vocab_size, (2, 4096), generator=g).cuda()
+    # batch 8 x 4096 tokens: the per-GPU batch of the data-parallel benchmark configuration (src/train_aria.py:273)
+    ids = torch.randint(3, cfg.vocab_size, (8, 4096), generator=g).cuda()
     lab = ids.clone()
-    lab[0, :700] = -100                                   # prompt span masked, as the melody collate does
+    lab[:, :1024] = -100                                  # first quarter of every row masked (the prompt span)
+    lab[0, :1700] = -100
     tr = Trainer(m, lr=1e-4, num_epochs=1, steps_per_epoch=100, warmup=1, max_grad_norm=1.0)
     losses = [float(tr.training_step({"input_ids": ids, "labels": lab})) for _ in range(4)]
     # random init: unit-RMS hidden states times N(0, 0.02^2) head rows give logits ~ N(0, d * 0.02^2), so the loss
