@@ -1,0 +1,65 @@
+"""Batches of 64 streams or more are decoded as two halves on two HIP streams. Every stream's tokens must be what
+the one-part path produces: greedy, sampled from the Philox stream (row base of the second half), sampled from explicit
+noise, with EOS / pad bookkeeping, with an odd number of streams, and with the per-step logits returned."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    from mgen import MidiLM, LMConfig
+    cfg = LMConfig(vocab_size=2048, hidden_size=512, intermediate_size=2048, num_hidden_layers=2,
+                   num_attention_heads=4, num_key_value_heads=2, head_dim=128)
+    return MidiLM(cfg, device="cuda:0", seed=3)
+
+
+def _both(fn):
+    os.environ["MGEN_DECODE_PARTS"] = "1"
+    try:
+        one = fn()
+    finally:
+        os.environ.pop("MGEN_DECODE_PARTS", None)
+    two = fn()
+    torch.cuda.synchronize()
+    return one, two
+
+
+@pytest.mark.parametrize("B", [64, 65, 130])
+def test_greedy_and_philox_sampling(model, B):
+    g = torch.Generator().manual_seed(B)
+    prompt = torch.randint(3, 2048, (B, 5), generator=g).cuda()
+    one, two = _both(lambda: model.generate(prompt, max_new_tokens=24, do_sample=False))
+    assert torch.equal(one, two)
+    one, two = _both(lambda: model.generate(prompt, max_new_tokens=24, do_sample=True, temperature=0.9, top_k=0,
+                                            top_p=0.9, seed=77))
+    assert torch.equal(one, two)
+    assert not torch.equal(one[:B // 2, 5:], one[B - B // 2:, 5:]), "the two halves drew the same noise"
+
+
+def test_explicit_noise_and_step_logits(model):
+    B, V, n = 64, 2048, 6
+    g = torch.Generator().manual_seed(1)
+    prompt = torch.randint(3, V, (B, 3), generator=g).cuda()
+    noise = torch.empty(n, B, V).exponential_(1.0, generator=g).cuda()
+    (o1, l1), (o2, l2) = _both(lambda: model.generate(prompt, max_new_tokens=n, do_sample=True, top_k=20, noise=noise,
+                                                      return_step_logits=True))
+    assert torch.equal(o1, o2)
+    assert l1.shape == l2.shape == (n, B, V) and torch.equal(l1, l2)
+
+
+def test_eos_and_pad_bookkeeping(model):
+    B = 96
+    g = torch.Generator().manual_seed(2)
+    prompt = torch.randint(3, 2048, (B, 4), generator=g).cuda()
+    free = model.generate(prompt, max_new_tokens=40, do_sample=True, temperature=1.0, top_k=0, seed=5)
+    eos = int(free[3, 10])     # a token stream 3 produces early becomes the EOS id: rows finish at different steps
+    one, two = _both(lambda: model.generate(prompt, max_new_tokens=40, do_sample=True, temperature=1.0, top_k=0, seed=5,
+                                            eos_token_id=eos, pad_token_id=0, eos_check_every=4))
+    assert torch.equal(one, two)
+    row = two[3, 4:]
+    first = int((row == eos).nonzero()[0])
+    assert first <= 6 and bool((row[first + 1:] == 0).all())
