@@ -141,12 +141,12 @@ def launch_ranks_if_needed(args):
         world = int(os.environ["WORLD_SIZE"])
         if world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.gpus == 1 or "WORLD_SIZE" in os.environ:
+        return   # (under a launcher the ranks' device visibility is the launcher's business: it may show each rank one GPU)
     have = torch.cuda.device_count()     # counts devices without creating a GPU context
     if args.gpus > have and not rehearse:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible "
                          "(MGEN_REHEARSE_ON_ONE_GPU=1 puts every rank on device 0 for a control-flow rehearsal)")
-    if args.gpus == 1 or "WORLD_SIZE" in os.environ:
-        return
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -377,6 +377,20 @@ int mgen_attn_decode(const void* q, long ld_q, const void* k_cache, const void* 
                      long ld_o, float* workspace, int B, int H, int KVH, int D, int max_len, int nsplit, float scale,
                      mgen_stream_t stream);
 
+/* One decoder layer of the one-token decode step in one call (seven launches issued by the library): QKV projection,
+ * mgen_attn_decode_prep, o_proj slabs, slab sum + residual + post-attention norm, gate/up projection, down projection
+ * with the gated operand, slab sum + residual + the norm that follows the layer. x (bf16 [B][d]) holds the layer's
+ * normed input on entry and the next norm's output on return; h_in / h_mid / h_out are the fp32 residual stream before,
+ * inside and after the layer; qkv, att, gu, slabs ([max(H*D, I)/512][B][d] fp32) are scratch. For RMSNorm blocks whose
+ * four projections fit mgen_gemm_bf16_skinny (mgen_decode_layer_fits). Replaces Qwen3DecoderLayer.forward at
+ * q_len = 1 with a cache (TF models/qwen3/modeling_qwen3.py:294-323, cache_utils.py:127-146). */
+int mgen_decode_layer_fits(int B, int d, int H, int KVH, int D, int I);
+int mgen_decode_layer(void* x, const float* h_in, float* h_mid, float* h_out, void* qkv, void* att, void* gu,
+                      float* slabs, float* attn_workspace, const void* w_qkv, const float* w_qn, const float* w_kn,
+                      const void* w_o, const float* w_ln2, const void* w_gu, const void* w_down, const float* w_next,
+                      const float* cos_sin, const int* pos, const int* kv_len, void* k_cache, void* v_cache, int B,
+                      int d, int H, int KVH, int D, int I, int max_len, int nsplit, float eps, int interleaved,
+                      mgen_stream_t stream);
 /* mgen_decode_qkv_prep + mgen_attn_decode in one launch: q, the new key and the new value are taken from the raw
  * projection rows qkv [B][ld_in] inside the attention kernel (same bits as the two calls). kv_len[b] counts the new
  * token; the caches are read up to kv_len[b] - 1 keys and receive the new rows at slot pos[b]. */

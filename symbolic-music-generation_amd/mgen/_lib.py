@@ -88,6 +88,7 @@ SIGNATURES = {
     "mgen_kv_append": [P, P, L, L, P, P, P, I, I, I, I, I, P],
     "mgen_attn_decode": [P, L, P, P, P, P, L, P, I, I, I, I, I, I, F, P],
     "mgen_gemm_bf16_skinny": [P, P, P, I, I, I, L, L, L, I, L, I, P],
+    "mgen_decode_layer": [P] * 22 + [I] * 8 + [F, I, P],
     "mgen_decode_qkv_prep": [P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, I, P],
     "mgen_attn_decode_prep": [P, L, P, P, P, P, F, I, P, P, P, P, L, P, I, I, I, I, I, I, F, P],
     "mgen_sample_rows": [P, L, I, I, I, I, F, I, F, P, L, U64, U64, I, P, P, L, P],
@@ -122,6 +123,8 @@ def lib():
         l.mgen_gemm_slab_count.restype = ctypes.c_int
         l.mgen_lmhead_ce_workspace_bytes.argtypes = [L, I, L]
         l.mgen_lmhead_ce_workspace_bytes.restype = ctypes.c_long
+        l.mgen_decode_layer_fits.argtypes = [I] * 6
+        l.mgen_decode_layer_fits.restype = ctypes.c_int
         l.mgen_gemm_skinny_fits.argtypes = [I, I, I, L, L, L, I]
         l.mgen_gemm_skinny_fits.restype = ctypes.c_int
         l.mgen_attn_decode_workspace.argtypes = [I, I, I, I]

@@ -57,6 +57,8 @@ class _Part:
 
 # batches of at least this many streams are decoded as two halves on two HIP streams (MGEN_DECODE_PARTS=1: never)
 _TWO_PART_MIN_STREAMS = 64
+# MGEN_DECODE_LAYER_C=0: issue the launches of a decode layer one by one from Python (for measurements)
+_LAYER_IN_ONE_CALL = os.environ.get("MGEN_DECODE_LAYER_C", "1") != "0"
 
 
 class _DecodeBuffers:
@@ -88,6 +90,7 @@ class _DecodeBuffers:
         self.ns_o = HD // 512 if self.sk_o else ops.gemm_slab_count(HD)
         self.ns_d = I // 512 if self.sk_down else ops.gemm_slab_count(I)
         self.slabs = torch.empty(max(self.ns_o, self.ns_d), B, d, dtype=f32, device=dev)
+        self.layer_args = {}
         if cfg.pos4d:
             self.rot = torch.empty(B, cfg.qkv_width, dtype=bf, device=dev)
             self.pairs = torch.empty(B, 16, dtype=bf, device=dev)
@@ -124,6 +127,23 @@ class GenerationMixin:
         pos = lens[t]          # int32 [>= B] = t
         kv_len = lens[t + 1]   # int32 [>= B] = t + 1
         h = buf.h
+        if _LAYER_IN_ONE_CALL and buf.sk_qkv and buf.sk_gu and buf.sk_o and buf.sk_down and not self._ln:
+            # every launch of the layer issued by one library call (the pointer arguments are collected once per
+            # layer and buffer set: only the position, the split count and the stream change from step to step)
+            key = (l, cache.k[l].data_ptr())
+            fixed = buf.layer_args.get(key)
+            nxt = buf.h2 if h is buf.h0 else buf.h0
+            if fixed is None:
+                w_next = self._layers[l + 1].w_ln1 if l + 1 < L else self.model.norm.weight
+                fixed = buf.layer_args[key] = (
+                    [t_.data_ptr() for t_ in (buf.x, h, buf.h1, nxt, buf.qkv, buf.att, buf.gu, buf.slabs, ws, v.s_qkv)]
+                    + [0 if v.w_qn is None else v.w_qn.data_ptr(), 0 if v.w_kn is None else v.w_kn.data_ptr()]
+                    + [t_.data_ptr() for t_ in (v.s_o, v.w_ln2, v.s_gu, v.s_down, w_next)],
+                    [cache.k[l].data_ptr(), cache.v[l].data_ptr(), B, d, H, KVH, Dh, I, cache.max_len])
+            ops.decode_layer(fixed[0], self._rope_cs.data_ptr(), pos.data_ptr(), kv_len.data_ptr(), fixed[1],
+                             self._decode_split(B, t + 1), eps, int(cfg.rope_interleaved))
+            buf.h = nxt
+            return
         if buf.sk_qkv:
             ops.linear_skinny(buf.x, v.s_qkv, buf.qkv)
         else:
@@ -248,7 +268,8 @@ class GenerationMixin:
         # lens[t] = int32 [B] filled with t: per-stream positions / key counts without per-step host->device traffic
         lens = torch.arange(total + 1, dtype=torch.int32, device=dev)[:, None].expand(total + 1, B).contiguous()
         self._rope_table(total)          # sized once, before any side stream reads it
-        nparts = 2 if (B >= _TWO_PART_MIN_STREAMS and os.environ.get("MGEN_DECODE_PARTS", "2") != "1") else 1
+        # (MGEN_DECODE_PARTS=n: n parts of at least 32 streams, for measurements; 3 and 4 parts measured no better than 2)
+        nparts = max(1, min(int(os.environ.get("MGEN_DECODE_PARTS", "2")), B // 32)) if B >= _TWO_PART_MIN_STREAMS else 1
         main = torch.cuda.current_stream()
         nxt_all = torch.empty(B, dtype=torch.int64, device=dev)
         parts = []

@@ -568,6 +568,13 @@ def attn_decode_prep(qkv, ld_in, wq, wk, cs, pos, eps, interleaved, k_cache, v_c
          _p(v_cache), _p(kv_len), _p(out), ld_o, _p(workspace), B, H, KVH, D, max_len, nsplit, scale, _stream())
 
 
+def decode_layer(ptrs17, cos_sin, pos, kv_len, cache_and_shape, nsplit, eps, interleaved):
+    """One decoder layer of the one-token step in one library call. ptrs17: raw pointers x, h_in, h_mid, h_out, qkv,
+    att, gu, slabs, attention workspace, w_qkv, w_qn, w_kn, w_o, w_ln2, w_gu, w_down, w_next; cache_and_shape:
+    k_cache, v_cache pointers then B, d, H, KVH, D, I, max_len."""
+    call("mgen_decode_layer", *ptrs17, cos_sin, pos, kv_len, *cache_and_shape, nsplit, eps, interleaved, _stream())
+
+
 def attn_decode_workspace(B, H, D, nsplit):
     from ._lib import lib
     return lib().mgen_attn_decode_workspace(B, H, D, nsplit)

@@ -217,6 +217,8 @@ def init_distributed_from_env():
     if rehearse:
         local = 0
     if torch.cuda.is_available():
+        if torch.cuda.device_count() == 1:
+            local = 0   # a launcher that shows every rank only its own GPU
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         backend = "nccl" if torch.cuda.is_available() and not rehearse else "gloo"

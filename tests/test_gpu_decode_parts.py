@@ -63,3 +63,28 @@ def test_eos_and_pad_bookkeeping(model):
     row = two[3, 4:]
     first = int((row == eos).nonzero()[0])
     assert first <= 6 and bool((row[first + 1:] == 0).all())
+
+
+@pytest.mark.parametrize("B", [3, 64, 130])
+def test_layer_in_one_call_equals_launch_by_launch(model, B, monkeypatch):
+    """mgen_decode_layer issues the same seven launches a decode layer makes one by one: same tokens, same logits."""
+    from mgen import generation
+    g = torch.Generator().manual_seed(10 + B)
+    prompt = torch.randint(3, 2048, (B, 7), generator=g).cuda()
+    assert generation._LAYER_IN_ONE_CALL
+    o1, l1 = model.generate(prompt, max_new_tokens=12, do_sample=False, return_step_logits=True)
+    monkeypatch.setattr(generation, "_LAYER_IN_ONE_CALL", False)
+    o2, l2 = model.generate(prompt, max_new_tokens=12, do_sample=False, return_step_logits=True)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+
+
+def test_decode_layer_rejects_shapes_it_does_not_take():
+    from mgen import ops
+    from mgen._lib import lib
+    assert lib().mgen_decode_layer_fits(128, 512, 8, 8, 128, 2048) == 1
+    assert lib().mgen_decode_layer_fits(128, 768, 8, 8, 128, 2048) == 0      # hidden size not one 512 slice
+    assert lib().mgen_decode_layer_fits(128, 512, 8, 8, 128, 1000) == 0      # intermediate size not whole slices
+    x = torch.zeros(8, device="cuda")
+    with pytest.raises(RuntimeError, match="shapes not taken"):
+        ops.decode_layer([x.data_ptr()] * 17, x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                         [x.data_ptr(), x.data_ptr(), 4, 768, 8, 8, 128, 2048, 64], 1, 1e-6, 0)
