@@ -358,17 +358,25 @@ def sample_with_noise(scores: torch.Tensor, noise: torch.Tensor) -> torch.Tensor
 def generate(p, cfg: LMConfig, input_ids: torch.Tensor, max_new_tokens: int, do_sample: bool = False,
              temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, eos_token_id: Optional[int] = None,
              pad_token_id: Optional[int] = None, noise: Optional[torch.Tensor] = None, mode: str = "fp32",
-             return_logits: bool = False):
-    """KV-cached sampling loop. noise [steps,B,V] Exp(1) draws when do_sample. Returns ids [B, prompt+new]."""
+             return_logits: bool = False, attention_mask: Optional[torch.Tensor] = None):
+    """KV-cached sampling loop. noise [steps,B,V] Exp(1) draws when do_sample. Returns ids [B, prompt+new].
+    attention_mask [B, prompt] (1 = real token; left padding for batched prompts): padded keys stay masked at every
+    step, the mask grows by a column of ones per token, and positions count real tokens only
+    (position_ids = cumsum(mask) - 1, 1 where masked: transformers generation/utils.py
+    _update_model_kwargs_for_generation and prepare_inputs_for_generation)."""
     B = input_ids.shape[0]
     cache = KVCache()
     unfinished = torch.ones(B, dtype=torch.long)
     ids = input_ids
     cur = input_ids
     all_logits = []
+    mask = attention_mask.long() if attention_mask is not None else None
     for t in range(max_new_tokens):
+        pos = None
+        if mask is not None:
+            pos = (mask.cumsum(-1) - 1).masked_fill(mask == 0, 1)[:, -cur.shape[1]:]
         with torch.no_grad():
-            hN = forward_hidden(p, cfg, cur, None, mode, cache)
+            hN = forward_hidden(p, cfg, cur, mask, mode, cache, position_ids=pos)
             logits = linear(hN[:, -1:, :], lm_head_weight(p, cfg), mode)[:, 0, :].float()
         if return_logits:
             all_logits.append(logits)
@@ -381,6 +389,8 @@ def generate(p, cfg: LMConfig, input_ids: torch.Tensor, max_new_tokens: int, do_
             unfinished = unfinished & (nxt != eos_token_id).long()
         ids = torch.cat([ids, nxt[:, None]], dim=1)
         cur = nxt[:, None]
+        if mask is not None:
+            mask = torch.cat([mask, torch.ones(B, 1, dtype=torch.long)], dim=1)
         if eos_token_id is not None and int(unfinished.max()) == 0:
             break
     if return_logits:

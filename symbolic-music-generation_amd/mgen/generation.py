@@ -203,7 +203,14 @@ class GenerationMixin:
                  do_sample: bool = False, temperature: float = 1.0, top_k: Optional[int] = None, top_p: float = 1.0,
                  pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None, use_cache: bool = True,
                  noise: Optional[torch.Tensor] = None, seed: int = 0, eos_check_every: int = 16,
-                 return_step_logits: bool = False, **unused):
+                 return_step_logits: bool = False, attention_mask: Optional[torch.Tensor] = None, **unused):
+        """attention_mask [B, prompt_len] (1 = real token): prompts of different lengths batched with LEFT padding, as
+        transformers' generate() expects of a decoder-only model (generation/utils.py: the mask grows by a column of
+        ones per token, position ids count real tokens only). Each stream then produces what it would produce alone
+        from its unpadded prompt: internally the rows are shifted to start at column 0, the prefill runs on the shifted
+        batch (causal attention keeps the tail a shorter row carries out of its real tokens' sight) and every stream
+        decodes at its own position. Right padding in generate() is refused (the reference library would continue such a row
+        from a padding token)."""
         if input_ids is None or input_ids.dim() != 2:
             raise ValueError("generate() needs input_ids of shape [batch, prompt_len]")
         if not input_ids.is_cuda:
@@ -236,6 +243,25 @@ class GenerationMixin:
         self.sync_shadow()
         out = torch.empty(B, total, dtype=torch.int64, device=dev)
         out[:, :P] = input_ids
+        # ---- left-padded prompts: n_real[b] real tokens at the END of row b; `prompt` holds them from column 0 on
+        n_real = None          # int64 [B], None when every row is P long
+        prompt = input_ids
+        rows = None
+        if attention_mask is not None:
+            if tuple(attention_mask.shape) != (B, P):
+                raise ValueError("attention_mask must have the shape of input_ids")
+            am = attention_mask.to(device=dev, dtype=torch.int64)
+            n = am.sum(1)
+            zeros_then_ones = (am[:, 1:] >= am[:, :-1]).all() if P > 1 else torch.ones((), dtype=torch.bool, device=dev)
+            n_min, n_max, ok = torch.stack([n.min(), n.max(), zeros_then_ones.long()]).tolist()
+            if not (ok and n_min >= 1 and int(am.max()) <= 1 and int(am.min()) >= 0):
+                raise ValueError("generate() takes prompts padded on the LEFT: every attention_mask row must be zeros "
+                                 "followed by at least one 1")
+            if n_min < P:
+                n_real = n
+                rows = torch.arange(B, device=dev)
+                shift = (torch.arange(P, device=dev)[None, :] + (P - n)[:, None]).clamp_(max=P - 1)
+                prompt = input_ids.gather(1, shift)   # past its real tokens a row repeats its last token (never seen)
         if not use_cache or getattr(self, "act_dtype", torch.bfloat16) == torch.float32:
             # no cache (and the fp32 parity mode, whose cache-less arithmetic is the reference's own): every step
             # runs the whole prefix through the training forward and keeps the last row of logits
@@ -243,9 +269,16 @@ class GenerationMixin:
             unfinished = torch.ones(B, dtype=torch.int64, device=dev) if eos_token_id is not None else None
             step_logits = [] if return_step_logits else None
             n_done = 0
+            seq = out
+            if n_real is not None:     # the shifted rows grow at their own ends; columns past an end hold token 0
+                seq = torch.zeros(B, total, dtype=torch.int64, device=dev)
+                seq[:, :P] = prompt
             for step in range(max_new_tokens):
-                xN, _ = self._run_layers(out[:, :P + step].contiguous(), save=None)
-                last = xN.view(B, P + step, -1)[:, -1, :].contiguous()
+                xN, _ = self._run_layers(seq[:, :P + step].contiguous(), save=None)
+                if n_real is None:
+                    last = xN.view(B, P + step, -1)[:, -1, :].contiguous()
+                else:
+                    last = xN.view(B, P + step, -1)[rows, n_real + step - 1].contiguous()
                 logits = self._logits(last)
                 ld = logits.stride(0)
                 full = logits.as_strided((B, ld), (ld, 1))
@@ -258,6 +291,8 @@ class GenerationMixin:
                     tok = nxt * unfinished + pad_token_id * (1 - unfinished)
                     unfinished.mul_((tok != eos_token_id).long())
                 out[:, P + step] = tok
+                if n_real is not None:
+                    seq[rows, n_real + step] = tok
                 n_done = step + 1
                 if unfinished is not None and int(unfinished.max()) == 0:
                     break
@@ -267,9 +302,13 @@ class GenerationMixin:
         cache = KVCache(cfg, B, total, dev)
         # lens[t] = int32 [B] filled with t: per-stream positions / key counts without per-step host->device traffic
         lens = torch.arange(total + 1, dtype=torch.int32, device=dev)[:, None].expand(total + 1, B).contiguous()
+        if n_real is not None:   # stream b is (P - n_real[b]) positions behind the column count
+            lens = (lens - (P - n_real).to(torch.int32)[None, :]).clamp_(min=0)
         self._rope_table(total)          # sized once, before any side stream reads it
         # (MGEN_DECODE_PARTS=n: n parts of at least 32 streams, for measurements; 3 and 4 parts measured no better than 2)
         nparts = max(1, min(int(os.environ.get("MGEN_DECODE_PARTS", "2")), B // 32)) if B >= _TWO_PART_MIN_STREAMS else 1
+        if type(self)._decode_step is not GenerationMixin._decode_step:
+            nparts = 1           # a model with its own one-token step (GPT-2) decodes the batch whole
         main = torch.cuda.current_stream()
         nxt_all = torch.empty(B, dtype=torch.int64, device=dev)
         parts = []
@@ -279,6 +318,7 @@ class GenerationMixin:
                                              self._decode_split(b1 - b0, total))
             parts.append(_Part(cfg, cache, b0, b1, nxt_all, ws_n, dev,
                                main if nparts == 1 else torch.cuda.Stream(device=dev)))
+            parts[-1].lens = lens[:, b0:b1]      # row t of the view: positions of the part's streams, contiguous
         unfinished = torch.ones(B, dtype=torch.int64, device=dev) if eos_token_id is not None else None
         step_logits = [[] for _ in parts] if return_step_logits else None
 
@@ -298,8 +338,11 @@ class GenerationMixin:
                 unf.mul_((tok != eos_token_id).long())
 
         # ---- prefill: the training forward on the prompt, K/V written into the cache
-        xN, _ = self._run_layers(input_ids.contiguous(), save=None, cache=cache)
-        last = xN.view(B, P, -1)[:, -1, :].contiguous()
+        xN, _ = self._run_layers(prompt.contiguous(), save=None, cache=cache)
+        if n_real is None:
+            last = xN.view(B, P, -1)[:, -1, :].contiguous()
+        else:
+            last = xN.view(B, P, -1)[rows, n_real - 1].contiguous()
         W = self._view(self.flat_shadow, self._lm_head_name())
         ldv = parts[0].buf.ldv
         logits0 = parts[0].buf.logits if nparts == 1 else torch.empty(B, ldv, dtype=torch.bfloat16, device=dev)
@@ -321,7 +364,7 @@ class GenerationMixin:
             t = P + step - 1
             if nparts == 1:
                 pt = parts[0]
-                logits = self._decode_step(pt.buf.next, pt.cache, t, pt.buf, lens, pt.ws)
+                logits = self._decode_step(pt.buf.next, pt.cache, t, pt.buf, pt.lens, pt.ws)
                 pick(logits, step, 0, B, pt.buf.next, step_logits[0] if return_step_logits else None)
             else:
                 # The launches of the two halves are issued layer by layer in turn, each half on its own stream.
@@ -334,7 +377,7 @@ class GenerationMixin:
                     for l in range(L):
                         for pt in parts:
                             ops.use_stream(pt.stream.cuda_stream)
-                            self._decode_layer(l, pt.cache, t, pt.buf, lens, pt.ws)
+                            self._decode_layer(l, pt.cache, t, pt.buf, pt.lens, pt.ws)
                     for pt in parts:
                         ops.use_stream(pt.stream.cuda_stream)
                         self._decode_end(pt.buf)

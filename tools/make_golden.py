@@ -234,6 +234,76 @@ def full_dq_case():
     print("dq_full_c1 loss", out["loss"], "gnorm", out["grad_norm"])
 
 
+def leftpad_case(name="leftpad_qwen3"):
+    """Batched generation from LEFT-padded prompts (the batched-prompt form of GenerationMixin.generate: position ids
+    from the mask's running sum, padded keys masked for every later step), tiny Qwen3 in fp32: greedy tokens, the
+    per-step logits margin, and a sampled run with injected noise."""
+    cfg = R.LMConfig(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                     num_attention_heads=2, num_key_value_heads=2, head_dim=128)
+    params = R.init_params(cfg, seed=0)
+    g = torch.Generator().manual_seed(7)
+    for k in params:
+        if "norm" in k:
+            params[k] = 1.0 + 0.1 * torch.randn(params[k].shape, generator=g)
+    m = hf_qwen3(cfg, params).eval()
+    gen = torch.Generator().manual_seed(99)
+    B, P, steps = 4, 12, 40
+    ids = torch.randint(3, cfg.vocab_size, (B, P), generator=gen)
+    mask = torch.ones(B, P, dtype=torch.long)
+    for b, pad in enumerate((0, 5, 11, 2)):
+        mask[b, :pad] = 0
+        ids[b, :pad] = 0
+    out = {"param_checksum": checksum(params), "input_ids": ids.numpy(), "attention_mask": mask.numpy()}
+    with torch.no_grad():
+        gtok = m.generate(ids, attention_mask=mask, max_new_tokens=steps, do_sample=False, eos_token_id=None,
+                          pad_token_id=0, use_cache=True)
+    out["greedy_tokens"] = gtok.numpy()
+    # each row generated alone from its unpadded prompt must give the same tokens (what left padding means)
+    for b in range(B):
+        n = int(mask[b].sum())
+        with torch.no_grad():
+            alone = m.generate(ids[b:b + 1, P - n:], max_new_tokens=steps, do_sample=False, eos_token_id=None,
+                               pad_token_id=0, use_cache=True)
+        assert torch.equal(alone[0, n:], gtok[b, P:]), b
+    # top1 - top2 gap of every chosen token (teacher-forced on the unpadded rows), for tie diagnostics
+    margins = []
+    for b in range(B):
+        n = int(mask[b].sum())
+        row = gtok[b:b + 1, P - n:]
+        with torch.no_grad():
+            lg = m(input_ids=row[:, :-1]).logits[0, n - 1:, :]
+        top2 = torch.topk(lg, 2, dim=-1)[0]
+        margins.append((top2[:, 0] - top2[:, 1]).numpy())
+    out["greedy_margin"] = np.stack(margins)
+    ng = torch.Generator().manual_seed(4321)
+    noise = torch.empty(steps, B, cfg.vocab_size).exponential_(1.0, generator=ng)
+    it = iter(range(steps))
+    orig = torch.multinomial
+
+    def fake_multinomial(probs, num_samples, replacement=False, *, generator=None):
+        t = next(it)
+        return (probs / noise[t]).argmax(dim=-1, keepdim=True)
+
+    torch.multinomial = fake_multinomial
+    try:
+        with torch.no_grad():
+            stok = m.generate(ids, attention_mask=mask, max_new_tokens=steps, do_sample=True, temperature=0.97,
+                              top_p=0.95, eos_token_id=None, pad_token_id=0, use_cache=True)
+    finally:
+        torch.multinomial = orig
+    out["sample_tokens"] = stok.numpy()
+    out["noise_seed"] = 4321
+    # EOS bookkeeping with ragged prompts: a token row 1 emits early becomes the EOS id
+    eos = int(gtok[1, P + 3])
+    with torch.no_grad():
+        etok = m.generate(ids, attention_mask=mask, max_new_tokens=steps, do_sample=False, eos_token_id=eos,
+                          pad_token_id=0, use_cache=True)
+    out["eos_id"] = eos
+    out["eos_tokens"] = etok.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "greedy", gtok.shape, "min margin", float(out["greedy_margin"].min()), "eos run", etok.shape)
+
+
 def load_reference_pos4d():
     """Import the reference's own 4-D model module (the only in-tree arithmetic of the reference) and pull the two
     post-processing functions out of generate_music.py without importing that script (its top-level imports need
@@ -608,6 +678,9 @@ def collate_case(name="collate"):
 
 if __name__ == "__main__":
     print("transformers", transformers.__version__, "torch", torch.__version__)
+    if "--leftpad-only" in sys.argv:
+        leftpad_case()
+        sys.exit(0)
     if "--collate-only" in sys.argv:
         collate_case()
         sys.exit(0)
@@ -628,5 +701,6 @@ if __name__ == "__main__":
                         rope_theta=10000.0, tie_word_embeddings=False, qk_norm=False)
     tiny_case("tiny_llama", tiny_l, hf_llama, extra_keys=("lm_head.weight",))
     collate_case()
+    leftpad_case()
     if "--full" in sys.argv:
         full_dq_case()
