@@ -127,6 +127,13 @@ def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
             "sampling": "T=0.97 top_p=0.95 top_k=off philox(seed 1234)", "out_shape": list(out.shape)}
 
 
+def nccl_version():
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:   # a report field must not cost the run its result line
+        return f"unknown ({type(e).__name__})"
+
+
 def launch_ranks_if_needed(args):
     """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process (which has not touched
     the GPU) starts N fresh rank processes through torch.distributed.run with the same arguments, relays their
@@ -319,8 +326,7 @@ def main():
             log = list(trainer.reducer.bucket_log)
             out["comm"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                            "ranks_seen": ranks_seen,
-                           "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())
-                           if dist.get_backend() == "nccl" else None,
+                           "nccl_version": nccl_version() if dist.get_backend() == "nccl" else None,
                            "collective": "all_reduce(AVG)" if trainer.reducer._native_avg else "all_reduce(SUM) / N",
                            "path": "mgen_comm (RCCL through the C-ABI)" if trainer.reducer._comm is not None
                            else "torch.distributed",

@@ -77,19 +77,30 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     }
 }
 
-// Copies of the gain-gradient row that the blocks of one mgen_rmsnorm_bwd launch add into, and the ticket counter of
-// that launch; all zero between launches. The device array holds NORM_DW_SLOTS such sets: the entry point gives every
-// (device, stream) pair a set of its own, so launches that overlap on one GPU (different streams) never share one, and
-// launches on one stream are ordered. A stream that finds every set taken runs the DIRECT form (atomics straight into
-// dw: no shared state at all).
-constexpr int NORM_DW_COPIES = 8;
-constexpr int NORM_DW_SLOTS = 16;
-static __device__ float g_dw_copies[NORM_DW_SLOTS * NORM_DW_COPIES * 2048];
-static __device__ unsigned g_dw_ticket[NORM_DW_SLOTS];
+// Gain gradient of mgen_rmsnorm_bwd. Every workgroup of a launch leaves its partial gain-gradient row in a row of its
+// own in a device array (plain stores), and a second small launch on the same stream adds the rows, column by column,
+// into dw: no atomics, so the result does not depend on the order the workgroups finish in. (fp32 atomics on device
+// memory run at 6-9 G/s on this GPU whatever the number of distinct addresses: one atomic per element and workgroup,
+// even spread over 8 copies of the row, cost 19 us of a 104 us launch at 256 workgroups x 512 columns and 134 of 241 us
+// at 768 x 1536.) The array holds NORM_DW_SLOTS such sets of rows: the entry point gives every (device, stream) pair a
+// set of its own, so launches that overlap on one GPU (different streams) never share one, and launches on one stream
+// are ordered. A stream that finds every set taken runs the DIRECT form (atomics straight into dw: no shared state).
+#ifndef MGEN_NORM_DW_MAXB
+#define MGEN_NORM_DW_MAXB 512
+#endif
+constexpr int NORM_DW_MAXB = MGEN_NORM_DW_MAXB;   // workgroups per launch at most
+constexpr int NORM_DW_SLOTS = 8;
+static __device__ float g_dw_rows[(long)NORM_DW_SLOTS * NORM_DW_MAXB * 2048];
 
 // Workgroups of 16 waves, one per CU (16 waves for rows of up to 512 elements; 4 for longer rows, whose per-lane
 // state needs more than 128 VGPRs).
-template <int VPL, typename DyT, bool DIRECT, int BWD_WAVES = (VPL <= 2 ? 16 : 4)>
+#ifndef MGEN_NB6_WAVES
+#define MGEN_NB6_WAVES 4
+#endif
+#ifndef MGEN_NB6_CAP
+#define MGEN_NB6_CAP 512
+#endif
+template <int VPL, typename DyT, bool DIRECT, int BWD_WAVES = (VPL <= 2 ? 16 : (VPL == 6 ? MGEN_NB6_WAVES : 4))>
 __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* __restrict__ dy,
                                                                      const float* __restrict__ x,
                                                                      const float* __restrict__ w,
@@ -145,10 +156,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* 
             }
         }
     }
-    // dw: the waves of the block meet in LDS; the blocks meet in NORM_DW_COPIES copies of the gain-gradient row kept
-    // in a device array (block b adds into copy b % NORM_DW_COPIES with atomics), and the block that draws the last
-    // ticket adds the copies to dw and clears them. (One atomic per element and block straight into dw serialises
-    // 256-512 adds on each of the same d addresses: 17 us of a 98 us launch at 256 blocks, 31 us at 512.)
+    // dw: the waves of the block meet in LDS; the block's row goes to its place in the slot's set of rows
+    float* myrow = g_dw_rows + ((long)slot * NORM_DW_MAXB + blockIdx.x) * 2048;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         __syncthreads();
@@ -158,37 +167,32 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* 
             f32x4 s = *reinterpret_cast<f32x4*>(&red[lane * 4]);
             for (int k = 1; k < BWD_WAVES; ++k) s += *reinterpret_cast<f32x4*>(&red[(k * 64 + lane) * 4]);
             const int c = (i * 64 + lane) * 4;
-            float* copy = DIRECT ? dw : g_dw_copies + ((long)slot * NORM_DW_COPIES + blockIdx.x % NORM_DW_COPIES) * 2048;
-            if (c < d)
-                for (int e = 0; e < 4; ++e) atomicAdd(copy + c + e, s[e]);
-            if (!DIRECT) __threadfence();   // every lane that added: its adds are performed before the block's ticket
-        }
-    }
-    if (DIRECT) return;
-    __shared__ int is_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        is_last = atomicAdd(&g_dw_ticket[slot], 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (is_last) {
-        __threadfence();
-        float* copies = g_dw_copies + (long)slot * NORM_DW_COPIES * 2048;
-        for (int col = threadIdx.x; col < d; col += blockDim.x) {
-            float v[NORM_DW_COPIES];
-#pragma unroll
-            for (int r = 0; r < NORM_DW_COPIES; ++r)
-                v[r] = __hip_atomic_load(&copies[r * 2048 + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            float acc = 0.f;
-#pragma unroll
-            for (int r = 0; r < NORM_DW_COPIES; ++r) {
-                acc += v[r];
-                copies[r * 2048 + col] = 0.f;   // clean for the next launch
+            if (c < d) {
+                if (DIRECT)
+                    for (int e = 0; e < 4; ++e) atomicAdd(dw + c + e, s[e]);
+                else
+                    *reinterpret_cast<f32x4*>(myrow + c) = s;
             }
-            dw[col] += acc;
         }
-        if (threadIdx.x == 0) g_dw_ticket[slot] = 0u;   // launches of one stream are ordered
+    }
+}
+
+// dw[col] += sum over the nblocks rows of the slot's set; one workgroup of 16 waves per 64 columns
+__global__ __launch_bounds__(1024) void rmsnorm_dw_reduce_kernel(float* __restrict__ dw, int d, int nblocks, int slot) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const float* rows = g_dw_rows + (long)slot * NORM_DW_MAXB * 2048;
+    float s = 0.f;
+    if (col < d)
+        for (int b = g; b < nblocks; b += 16) s += rows[(long)b * 2048 + col];
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && col < d) {
+        float t = part[0][lane];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += part[k][lane];
+        dw[col] += t;
     }
 }
 
@@ -211,16 +215,19 @@ int norm_dw_slot(hipStream_t stream) {
 template <int VPL, typename DyT>
 void launch_rmsnorm_bwd(hipStream_t stream, int slot, const void* dy, const float* x, const float* w,
                         const float* rstd, float* dres, void* dres_lp, float* dw, long T, int d, int accumulate) {
-    constexpr int NW = VPL <= 2 ? 16 : 4;
+    constexpr int NW = VPL <= 2 ? 16 : (VPL == 6 ? MGEN_NB6_WAVES : 4);
     const long b = (T + NW - 1) / NW;
-    // one 16-wave block per CU / three 4-wave blocks (rows of up to 1536: 3 waves per SIMD fit) / two 4-wave blocks
-    const long cap = VPL <= 2 ? 256 : (VPL <= 6 ? 768 : 512);
+    // one 16-wave block per CU / two 4-wave blocks (rows of up to 1536; three measured the same) / two 4-wave blocks
+    static_assert(MGEN_NB6_CAP <= NORM_DW_MAXB && 512 <= NORM_DW_MAXB, "a launch's workgroups need a row each");
+    const long cap = VPL <= 2 ? 256 : (VPL <= 6 ? MGEN_NB6_CAP : 512);
     const dim3 grid((int)(b < cap ? b : cap));
     const dim3 block(64 * NW);
-    if (slot >= 0)
+    if (slot >= 0) {
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, DyT, false>), grid, block, 0, stream, (const DyT*)dy, x, w, rstd,
                            dres, (DyT*)dres_lp, dw, T, d, accumulate, slot);
-    else
+        hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, dim3((d + 63) / 64), dim3(1024), 0, stream, dw, d, (int)grid.x,
+                           slot);
+    } else
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, DyT, true>), grid, block, 0, stream, (const DyT*)dy, x, w, rstd,
                            dres, (DyT*)dres_lp, dw, T, d, accumulate, 0);
 }
