@@ -276,9 +276,12 @@ __device__ __forceinline__ float key_val(unsigned k) {
     }
 #define MGEN_FOR_EACH_KEY(BODY) MGEN_FOR_EACH_KEY2(BODY, {})
 
+constexpr int SAMPLE_HB = 8192;          // histogram bins of the top-p search (64 KiB of dynamic LDS)
+
 __global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
     constexpr int NW = FNT / 64;
     __shared__ Red red;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];
     const int row_i = blockIdx.x, tid = threadIdx.x, V = a.V;
     const unsigned short* row = reinterpret_cast<const unsigned short*>(a.logits) + (long)row_i * a.ld;
 
@@ -366,42 +369,101 @@ __global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
         kcut = lo;
     }
 
-    // ---- normaliser of the top-k survivors and top-p: the smallest key x with mass{kcut <= key <= x} > (1-p) Z
+    // ---- normaliser Z of the top-k survivors and the top-p cut: the smallest key x with mass{kcut <= key <= x} >
+    // (1 - p) Z. One pass over the row sums Z and adds every survivor's e_i, as a 2^-40 fixed-point integer, into a
+    // histogram over the keys in LDS (integer adds: the bins do not depend on the order the lanes arrive in); a scan of
+    // the bins finds the one where the running mass passes the threshold. Key ranges wider than the histogram use
+    // bins of 2^shift keys and a second pass over the keys of the bin that was found.
     const float c2 = LOG2E;
-    unsigned lo = kcut, hi = kmax;           // answer in [lo, hi]; below = mass{kcut <= key < lo}
-    float below = 0.f, Z = 0.f, thr = 0.f;
-    bool first = true;
     const bool want_p = a.top_p < 1.0f;
-    while (first || (want_p && lo < hi)) {
-        const unsigned span = hi - lo;       // thresholds in [lo, hi); the first pass also measures Z at kmax
-        const unsigned m1 = lo + span / 4, m2 = lo + span / 2, m3 = first ? kmax : lo + span / 2 + span / 4;
+    float Z = 0.f;
+    unsigned long long below_fx = 0, thr_fx = 0;    // mass{kcut <= key < base}, threshold (both x 2^40)
+    unsigned base = kcut, nkeys = kmax - kcut + 1;  // the cut lies in [base, base + nkeys)
+    for (int level = 0;; ++level) {
+        int sh = 0;
+        while (((nkeys - 1) >> sh) >= (unsigned)SAMPLE_HB) ++sh;
+        const int nb = (int)((nkeys - 1) >> sh) + 1;
+        if (want_p) {
+            for (int i = tid; i < nb; i += FNT) hist[i] = 0ull;
+            __syncthreads();
+        }
         float f[3] = {0.f, 0.f, 0.f};
         MGEN_FOR_EACH_KEY({
-            const bool in = k >= lo && k <= m3;
+            const unsigned rel = k - base;           // (padding has key 0 < kcut: wraps far above nkeys)
+            const bool in = rel < nkeys;
             if (__builtin_amdgcn_ballot_w64(in) != 0ull) {
-                const float ee = in ? __builtin_amdgcn_exp2f((score(k) - smax) * c2) : 0.f;
-                f[2] += ee;
-                f[1] += k <= m2 ? ee : 0.f;
-                f[0] += k <= m1 ? ee : 0.f;
+                if (in) {
+                    const float ee = __builtin_amdgcn_exp2f((score(k) - smax) * c2);
+                    f[2] += ee;
+                    if (want_p) {
+                        // ee in [0, 1] as (hi, lo) = ee * 2^40 split at 2^32: both factors are powers of two (exact)
+                        const float e8 = ee * 256.0f;
+                        const float hi = __builtin_floorf(e8);
+                        const unsigned long long fx =
+                            ((unsigned long long)(unsigned)hi << 32) | (unsigned)((e8 - hi) * 4294967296.0f);
+                        atomicAdd(&hist[rel >> sh], fx);
+                    }
+                }
             }
         })
-        block_sum3<NW>(f, red);
-        if (first) {
+        if (level == 0) {
+            block_sum3<NW>(f, red);                  // (its barriers also end the histogram adds)
             Z = f[2];
-            thr = (1.0f - a.top_p) * Z;
-            first = false;
             if (!want_p) break;
-            if (f[0] > thr) hi = m1;
-            else if (f[1] > thr) { lo = m1 + 1; hi = m2; below += f[0]; }
-            else { lo = m2 + 1; below += f[1]; }
-            continue;
+            const double t = (double)((1.0f - a.top_p) * Z) * 1099511627776.0;
+            thr_fx = (unsigned long long)t;
+        } else {
+            __syncthreads();
         }
-        if (below + f[0] > thr) hi = m1;
-        else if (below + f[1] > thr) { lo = m1 + 1; hi = m2; below += f[0]; }
-        else if (below + f[2] > thr) { lo = m2 + 1; hi = m3; below += f[1]; }
-        else { lo = m3 + 1; below += f[2]; }
+        // thread t owns bins [t * per, t * per + per): block-exclusive prefix of the owners' sums, then the owner of
+        // the crossing walks its bins. The threshold is kept below the total, so a crossing exists (keep >= 1: the
+        // largest key always survives).
+        const int per = (nb + FNT - 1) / FNT;
+        unsigned long long mine = 0;
+        for (int j = 0; j < per; ++j) {
+            const int bi = tid * per + j;
+            if (bi < nb) mine += hist[bi];
+        }
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(incl, o, 64);
+            if ((tid & 63) >= o) incl += up;
+        }
+        if ((tid & 63) == 63) red.u[tid >> 6] = incl;
+        __syncthreads();
+        unsigned long long before = 0, total = 0;
+        for (int w = 0; w < NW; ++w) {
+            const unsigned long long tw = red.u[w];
+            if (w < (tid >> 6)) before += tw;
+            total += tw;
+        }
+        __syncthreads();                             // red.u is free again
+        if (level == 0 && thr_fx >= total) thr_fx = total - 1;   // (total >= 2^40: the largest key has e = 1)
+        const unsigned long long excl = below_fx + before + (incl - mine);
+        if (excl <= thr_fx && excl + mine > thr_fx) {   // exactly one thread
+            unsigned long long run = excl;
+            for (int j = 0; j < per; ++j) {
+                const int bi = tid * per + j;
+                const unsigned long long h = bi < nb ? hist[bi] : 0ull;
+                if (run + h > thr_fx) {
+                    red.u[0] = run;
+                    red.u[1] = (unsigned long long)bi;
+                    break;
+                }
+                run += h;
+            }
+        }
+        __syncthreads();
+        below_fx = red.u[0];
+        const unsigned bin = (unsigned)red.u[1];
+        __syncthreads();
+        base += bin << sh;
+        if (sh == 0) break;
+        nkeys = min(1u << sh, kmax - base + 1);
     }
-    if (want_p) kcut = lo;
+    if (want_p) kcut = base;
+    const float below = (float)((double)below_fx * (1.0 / 1099511627776.0));
     const float Zk = Z - below;              // mass of the final survivors
 
     // ---- the draw: argmax over the survivors of (e_i / Zk) / q_i; one Philox block serves 4 neighbouring elements
@@ -471,7 +533,22 @@ extern "C" int mgen_sample_rows(const void* logits, long ld, int B, int V, int i
     a.do_sample = do_sample; a.noise = noise; a.ld_noise = ld_noise; a.seed = seed; a.offset = offset; a.out = out;
     a.out2 = out2; a.out2_stride = out2_stride; a.row0 = (unsigned)row0;
     const bool fast = is_bf16 && V <= FAST_MAX_V && ld % 8 == 0 && ((uintptr_t)logits % 16) == 0;
-    if (fast) hipLaunchKernelGGL(sample_bf16_kernel, dim3(B), dim3(FNT), 0, stream, a);
+    if (fast) {
+        constexpr int lds = SAMPLE_HB * 8;
+        static bool asked[16] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+        if (!asked[dev]) {   // with the static part more than the default 64 KiB of LDS: asked for once per device
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_bf16_kernel),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) {
+                mgen_set_error("mgen_sample: cannot reserve %d bytes of LDS: %s", lds, hipGetErrorString(e));
+                return MGEN_ELAUNCH;
+            }
+            asked[dev] = true;
+        }
+        hipLaunchKernelGGL(sample_bf16_kernel, dim3(B), dim3(FNT), lds, stream, a);
+    }
     else if (is_bf16) hipLaunchKernelGGL((sample_kernel<bf16>), dim3(B), dim3(NT), 0, stream, a);
     else hipLaunchKernelGGL((sample_kernel<float>), dim3(B), dim3(NT), 0, stream, a);
     return mgen_check_launch("mgen_sample");

@@ -1,5 +1,6 @@
 """Decode-only benchmark (GPU box): bench.py's two decode legs without the training step.
-   python tools/bench_decode.py [repeats]      env: MGEN_DECODE_PARTS, MGEN_DECODE_CHAIN, MGEN_GEMM_SKINNY"""
+   python tools/bench_decode.py [repeats]      env: MGEN_DECODE_PARTS, MGEN_GEMM_SKINNY, LEGS=literal,long,short;
+   GREEDY=1 replaces the sampler by the argmax (what the step costs without the top-p search and the draw)"""
 import os
 import sys
 
@@ -14,6 +15,9 @@ from mgen import MidiLM, default_decoder  # noqa: E402
 dev = torch.device("cuda:0")
 cfg = default_decoder()
 model = MidiLM(cfg, device=dev, seed=0)
+if os.environ.get("GREEDY") == "1":
+    _generate = model.generate
+    model.generate = lambda *a, **k: _generate(*a, **{**k, "do_sample": False})
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 1):
     legs = os.environ.get("LEGS", "literal,long").split(",")
     msg = []
