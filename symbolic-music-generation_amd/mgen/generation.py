@@ -35,6 +35,12 @@ class KVCache:
     def bytes_per_token(self):
         return 2 * len(self.k) * self.k[0].shape[1] * self.k[0].shape[3] * 2
 
+    def first_streams(self, batch: int):
+        """The cache of the first `batch` streams (views; the row capacity, i.e. the pitch between heads, stays)."""
+        if batch == self.k[0].shape[0]:
+            return self
+        return _CachePart(self, 0, batch)
+
 
 class _CachePart:
     """Streams [b0, b1) of a KVCache (views: a stream's rows are contiguous)."""
@@ -43,6 +49,7 @@ class _CachePart:
         self.max_len = cache.max_len
         self.k = [t[b0:b1] for t in cache.k]
         self.v = [t[b0:b1] for t in cache.v]
+        self.zero_pos = cache.zero_pos[b0:b1]
 
 
 class _Part:
@@ -100,6 +107,20 @@ class _DecodeBuffers:
 
 class GenerationMixin:
     """Mixed into MidiLM."""
+
+    def reserve_kv_cache(self, batch: int, max_len: int):
+        """Serving: allocate the KV cache for `batch` streams of up to `max_len` tokens once and write to all of it, so
+        that generate() calls that fit (batch and total length not larger) neither allocate nor take the first-touch
+        page faults of fresh device memory (about 170 ms for the 60 GB of 256 streams x 4096 tokens of the default
+        decoder) inside their first step. Held until release_kv_cache()."""
+        dev = self.flat_shadow.device
+        cache = KVCache(self.cfg, batch, max_len, dev)
+        for t in cache.k + cache.v:
+            t.zero_()
+        self._kv_reserved = cache
+
+    def release_kv_cache(self):
+        self._kv_reserved = None
 
     def _decode_split(self, B, length):
         cfg = self.cfg
@@ -299,7 +320,11 @@ class GenerationMixin:
             out = out[:, :P + n_done]
             self._check_device_flags()
             return (out, torch.stack(step_logits, 0)) if return_step_logits else out
-        cache = KVCache(cfg, B, total, dev)
+        held = getattr(self, "_kv_reserved", None)
+        if held is not None and B <= held.k[0].shape[0] and total <= held.max_len and held.k[0].device == dev:
+            cache = held.first_streams(B)
+        else:
+            cache = KVCache(cfg, B, total, dev)
         # lens[t] = int32 [B] filled with t: per-stream positions / key counts without per-step host->device traffic
         lens = torch.arange(total + 1, dtype=torch.int32, device=dev)[:, None].expand(total + 1, B).contiguous()
         if n_real is not None:   # stream b is (P - n_real[b]) positions behind the column count

@@ -88,3 +88,21 @@ def test_decode_layer_rejects_shapes_it_does_not_take():
     with pytest.raises(RuntimeError, match="shapes not taken"):
         ops.decode_layer([x.data_ptr()] * 17, x.data_ptr(), x.data_ptr(), x.data_ptr(),
                          [x.data_ptr(), x.data_ptr(), 4, 768, 8, 8, 128, 2048, 64], 1, 1e-6, 0)
+
+
+def test_reserved_kv_cache_gives_the_same_tokens(model):
+    """generate() inside a reserved cache (more streams and a longer row capacity than the call needs) equals
+    generate() on a cache of its own, for a whole batch and for two parts; a call that does not fit allocates."""
+    g = torch.Generator().manual_seed(21)
+    for B in (3, 70):
+        prompt = torch.randint(3, 2048, (B, 6), generator=g).cuda()
+        want = model.generate(prompt, max_new_tokens=20, do_sample=True, top_k=0, top_p=0.9, seed=4)
+        model.reserve_kv_cache(80, 64)
+        try:
+            got = model.generate(prompt, max_new_tokens=20, do_sample=True, top_k=0, top_p=0.9, seed=4)
+            assert torch.equal(got, want)
+            too_long = model.generate(prompt, max_new_tokens=70, do_sample=False)      # 76 > 64: own cache
+            assert too_long.shape == (B, 76)
+        finally:
+            model.release_kv_cache()
+    assert model._kv_reserved is None
