@@ -232,16 +232,15 @@ __global__ __launch_bounds__(NT) void sample_kernel(SampleArgs a) {
 }
 
 // ---- register-resident kernel for bf16 rows -------------------------------------------------------------------
-// A bf16 row of up to NCH*4096 logits (155 648 >= the 151 936-entry vocabulary) is read from HBM once, 16 bytes per
-// lane per chunk, converted to 16-bit order-preserving keys with packed 16-bit arithmetic, and stays in 152 VGPRs
-// per thread (512 threads: 2 wavefronts per SIMD, 256 VGPRs each); every later pass works on registers. bf16 has
-// only 2^16 distinct values and the order of logit / T equals the order of the logit for T > 0, so thresholds are
-// searched over those keys. Counts are taken wave-wide on the scalar unit (ballot + popcount). Each mass pass
-// evaluates exp() only for elements inside the interval that is still open (the mass below it is carried as a
-// running base), so after the first pass nearly all wavefronts skip the transcendental. Padding (beyond V) has
-// key 0, below the key of every number, and is never counted, summed or drawn.
-constexpr int FNT = 512;
-constexpr int NCH = 38;
+// A bf16 row of up to NCH * FNT * 8 logits (155 648 >= the 151 936-entry vocabulary) is read from HBM once, 16 bytes
+// per lane per chunk, converted to 16-bit order-preserving keys with packed 16-bit arithmetic, and stays in 76 VGPRs
+// per thread (1024 threads: 4 wavefronts per SIMD, 128 VGPRs each; with 512 threads and 152 key registers a launch of
+// 128 rows took 158 us against 129); every later pass works on registers. bf16 has only 2^16 distinct values and the
+// order of logit / T equals the order of the logit for T > 0, so thresholds are searched over those keys. Counts are
+// taken wave-wide on the scalar unit (ballot + popcount). Padding (beyond V) has key 0, below the key of every
+// number, and is never counted, summed or drawn.
+constexpr int FNT = 1024;
+constexpr int NCH = 19;
 constexpr int FAST_MAX_V = NCH * FNT * 8;
 
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
@@ -468,7 +467,7 @@ __global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
 
     // ---- the draw: argmax over the survivors of (e_i / Zk) / q_i; one Philox block serves 4 neighbouring elements
     unsigned long long best = 0;
-#pragma unroll 2
+#pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
         const u32x4 kk = pk[c];
 #pragma unroll
