@@ -8,10 +8,11 @@
 // argmax_i(probs_i / q_i) with q_i ~ Exp(1). The draw is made here from EXPLICIT noise: either a caller-supplied
 // q[B][V], or q = -ln(u) from a counter-based Philox4x32-10 stream that mgen_philox_exponential can also write out.
 //
-// Thresholds instead of a sort: scores are mapped to order-preserving integer keys; the k-th largest key is found by
-// a 4-ary search on counts, and the top-p cut by a 4-ary search on the probability mass at or below a key (the
-// ascending cumulative sum of the reference, evaluated at a key). Elements with equal scores are kept or dropped
-// together (the reference's unstable sort leaves that case unspecified).
+// Thresholds instead of a sort: scores are mapped to order-preserving integer keys; the k-th largest key and the
+// top-p cut (the ascending cumulative sum of the reference, evaluated at a key) are found from histograms over the
+// keys - counts, and probability mass as fixed-point integers - in the register-resident kernel, and by 4-ary
+// searches on counts and masses in the generic one. Elements with equal scores are kept or dropped together (the
+// reference's unstable sort leaves that case unspecified).
 //
 // Two kernels: a register-resident one for bf16 rows of up to 155 648 entries (the row is read from HBM once), and
 // a generic one (fp32 logits, longer or unaligned rows) that streams the row from cache in every pass.
@@ -341,31 +342,71 @@ __global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
     };
     const float smax = score(kmax);
 
-    // ---- top-k: the largest key x with count{key >= x} >= k
+    // ---- top-k: the largest key x with count{key >= x} >= k. One pass counts the keys into a histogram in LDS, a scan
+    // from the top finds the bin where the running count reaches k; key ranges wider than the histogram use bins of
+    // 2^shift keys and a second pass over the keys of the bin that was found.
     unsigned kcut = kmin;
     if (a.top_k > 0 && a.top_k < V) {
-        unsigned lo = kmin, hi = kmax;       // answer in [lo, hi]; base = count{key > hi}
-        float base = 0.f;
-        const float kf = (float)a.top_k;
-        while (lo < hi) {
-            const unsigned span = hi - lo;   // thresholds in (lo, hi]
-            const unsigned m1 = lo + (span + 3) / 4, m2 = lo + (span + 1) / 2, m3 = hi - span / 4;
-            // k in [m, hi]  <=>  (k - m) <= (hi - m) as unsigned: one subtract + one compare + one add-with-carry
-            int n1 = 0, n2 = 0, n3 = 0;
-            const unsigned w1 = hi - m1, w2 = hi - m2, w3 = hi - m3;
-            MGEN_FOR_EACH_KEY2({
-                n1 += (k - m1) <= w1 ? 1 : 0;
-                n2 += (k - m2) <= w2 ? 1 : 0;
-                n3 += (k - m3) <= w3 ? 1 : 0;
-            }, { asm volatile("" : "+v"(n1), "+v"(n2), "+v"(n3)); })
-            float cnt[3] = {(float)n1, (float)n2, (float)n3};
-            block_sum3<NW>(cnt, red);        // counts < 2^24 are exact in fp32
-            if (base + cnt[2] >= kf) lo = m3;
-            else if (base + cnt[1] >= kf) { lo = m2; hi = m3 - 1; base += cnt[2]; }
-            else if (base + cnt[0] >= kf) { lo = m1; hi = m2 - 1; base += cnt[1]; }
-            else { hi = m1 - 1; base += cnt[0]; }
+        unsigned* cnt = reinterpret_cast<unsigned*>(hist);
+        const unsigned want = (unsigned)a.top_k;
+        unsigned above = 0;                              // count{key >= base + nkeys}
+        unsigned base = kmin, nkeys = kmax - kmin + 1;   // the answer lies in [base, base + nkeys)
+        for (;;) {
+            int sh = 0;
+            while (((nkeys - 1) >> sh) >= (unsigned)SAMPLE_HB) ++sh;
+            const int nb = (int)((nkeys - 1) >> sh) + 1;
+            for (int i = tid; i < nb; i += FNT) cnt[i] = 0u;
+            __syncthreads();
+            MGEN_FOR_EACH_KEY({
+                const unsigned rel = k - base;           // (padding has key 0 < kmin: wraps far above nkeys)
+                if (rel < nkeys) atomicAdd(&cnt[rel >> sh], 1u);
+            })
+            __syncthreads();
+            // thread t owns bins [t * per, t * per + per); counts above a thread's bins = total - inclusive prefix
+            const int per = (nb + FNT - 1) / FNT;
+            unsigned mine = 0;
+            for (int j = 0; j < per; ++j) {
+                const int bi = tid * per + j;
+                if (bi < nb) mine += cnt[bi];
+            }
+            unsigned incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o, 64);
+                if ((tid & 63) >= o) incl += up;
+            }
+            if ((tid & 63) == 63) red.u[tid >> 6] = incl;
+            __syncthreads();
+            unsigned before = 0, total = 0;
+            for (int w = 0; w < NW; ++w) {
+                const unsigned tw = (unsigned)red.u[w];
+                if (w < (tid >> 6)) before += tw;
+                total += tw;
+            }
+            __syncthreads();                             // red.u is free again
+            const unsigned over = above + (total - (before + incl));   // count of keys above this thread's bins
+            if (over < want && over + mine >= want) {    // exactly one thread (the row has more than k entries)
+                unsigned run = over;
+                for (int j = per - 1; j >= 0; --j) {
+                    const int bi = tid * per + j;
+                    const unsigned h = bi < nb ? cnt[bi] : 0u;
+                    if (run + h >= want) {
+                        red.u[0] = run;
+                        red.u[1] = (unsigned long long)bi;
+                        break;
+                    }
+                    run += h;
+                }
+            }
+            __syncthreads();
+            above = (unsigned)red.u[0];
+            const unsigned bin = (unsigned)red.u[1];
+            __syncthreads();
+            base += bin << sh;
+            if (sh == 0) break;
+            nkeys = min(1u << sh, kmax - base + 1);
         }
-        kcut = lo;
+        kcut = base;
     }
 
     // ---- normaliser Z of the top-k survivors and the top-p cut: the smallest key x with mass{kcut <= key <= x} >
