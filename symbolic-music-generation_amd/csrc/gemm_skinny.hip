@@ -1,105 +1,122 @@
 // Projections of the one-token decode step: C[M, N] = A[M, K] W[N, K]^T with few token rows (M = number of streams,
-// tens to a few hundred) and small weights (1-4 MB). Such a product moves almost nothing; what it costs is the number of
-// dependent memory round trips between its launch and its last store, each of which stretches when the attention
-// kernel of another batch part is saturating HBM beside it. So this kernel makes exactly one: a workgroup owns
-// 64 token rows x 64 output columns x 512 reduction indices, every thread requests all 32 of its 16-byte pieces of
-// the two operand tiles (128 KiB per workgroup) before it waits for the first, the tiles go to LDS (rows of 1 KiB,
-// 16-byte chunks XOR-swizzled by the row so that the 32 rows an MFMA operand read touches fall on different banks),
-// one barrier, 32 v_mfma_f32_32x32x16_bf16 per wave, store.
+// tens to a few hundred) and small weights (1-4 MB). Such a product moves almost nothing; what it costs is (i) the
+// number of dependent memory round trips between its launch and its last store and (ii) whether its workgroups find
+// room on the CUs at all: when the batch is decoded in two parts on two streams, the attention kernel of the other part
+// is resident on every CU (4 workgroups of 96 registers and 9.4 KiB of LDS each), and a workgroup that needs more
+// than the 128 registers per lane and 121 KiB of LDS that remain waits until that kernel has ended - the projections
+// of one part and the attention of the other then run one after the other instead of side by side.
+//
+// So: a workgroup owns 32 token rows x 64 output columns x 512 reduction indices; both operand tiles (96 KiB) are
+// requested at once by LDS-DMA (24 one-KiB row pieces per wave, no data registers: one round trip), rows of 1 KiB with
+// the 16-byte chunks XOR-swizzled by the row on the source address so that the 16 rows an MFMA operand read touches
+// fall on different banks; one barrier; 32 v_mfma_f32_16x16x32_bf16 per wave (wave w: output columns 16 w .. 16 w + 15,
+// reduction indices in ascending order: the same bits as the tile-loop kernel); store.
 //
 //   out bf16   (K == 512): C[m][n] rounded to bf16                                 QKV and gate/up projections
 //   out slabs  (K = z * 512): fp32 partial products slabs[z][M][N], summed by mgen_slab_resid_rmsnorm
 //                                                                                   o_proj and down_proj
-//   a_swiglu: the A operand is silu(gate) * up formed from gu[M][2K] while the tile is loaded (gate rounded to bf16
-//             after the silu, the product rounded to bf16: the arithmetic of mgen_swiglu_fwd), so the gated activation
-//             of the MLP is never written
+//   a_swiglu: the A operand is silu(gate) * up formed from gu[M][2K] on its way to LDS (through registers; gate rounded
+//             to bf16 after the silu, the product rounded to bf16: the arithmetic of mgen_swiglu_fwd), so the gated
+//             activation of the MLP is never written
 //
 // Reference: the four nn.Linear calls of a decoder layer with q_len = 1 (transformers models/qwen3/modeling_qwen3.py:
 // 252-254, 279, 81-83) under GenerationMixin._sample (generation/utils.py:2876-2937).
-#include "common.h"
+#include "lds_dma.h"
 
 namespace {
 
+typedef __attribute__((ext_vector_type(4))) float sk_f32x4;
+
 constexpr int SK_KC = 512;            // reduction indices per workgroup
-constexpr int SK_TM = 64, SK_TN = 64; // token rows and output columns per workgroup
+constexpr int SK_TM = 32, SK_TN = 64; // token rows and output columns per workgroup
 constexpr int SK_ROWB = SK_KC * 2;    // bytes per LDS row
-constexpr int SK_LDS = (SK_TM + SK_TN) * SK_ROWB;
+constexpr int SK_LDS = (SK_TM + SK_TN) * SK_ROWB;   // 96 KiB
 
 __device__ __forceinline__ int sk_off(int row, int chunk) { return row * SK_ROWB + ((chunk ^ (row & 15)) << 4); }
 
 template <bool SLABS, bool ASW>
-__global__ __launch_bounds__(256, 1) void gemm_skinny_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
+__global__ __launch_bounds__(256, 4) void gemm_skinny_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                              void* __restrict__ Cout, int M, int N, int K, long lda,
                                                              long ldw, long ldc, long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                          // token tile   [64][512] bf16
+    char* sA = smem;                          // token tile   [32][512] bf16
     char* sW = smem + SK_TM * SK_ROWB;        // weight tile  [64][512] bf16
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * SK_TM, n0 = blockIdx.y * SK_TN, z = blockIdx.z;
     const int k0 = z * SK_KC;
-    const int ch = tid & 63;                  // 16-byte chunk of the row this thread moves
-    const int r0 = tid >> 6;                  // first of its 16 rows (rows r0, r0 + 4, ...)
+    const unsigned lds0 = lds_addr(smem);
 
-    // ---- every load of the workgroup in flight at once
-    u32x4 wv[16], av[16], uv[ASW ? 16 : 1];
+    // ---- every load of the workgroup in flight at once: row r of a tile is one wave instruction (64 lanes x 16 bytes);
+    // LDS position p of row r receives source chunk p ^ (r & 15)
+    const u32x4 rsW = dma_rsrc(W + (long)n0 * ldw + k0, (unsigned)((63L * ldw + SK_KC) * 2));
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const int r = r0 + 4 * j;
-        wv[j] = *reinterpret_cast<const u32x4*>(W + (long)(n0 + r) * ldw + k0 + ch * 8);
+        const int r = wave + 4 * j;
+        dma_piece(rsW, (lane ^ (r & 15)) << 4, lds0 + SK_TM * SK_ROWB + r * SK_ROWB, (int)(r * ldw * 2));
     }
+    if (!ASW) {
+        const u32x4 rsA = dma_rsrc(A + k0, (unsigned)(((long)(M - 1) * lda + SK_KC) * 2));
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int r = min(m0 + r0 + 4 * j, M - 1);        // rows past M repeat the last row (never stored)
-        av[j] = *reinterpret_cast<const u32x4*>(A + (long)r * lda + k0 + ch * 8);
-        if (ASW) uv[j] = *reinterpret_cast<const u32x4*>(A + (long)r * lda + K + k0 + ch * 8);
-    }
-    __builtin_amdgcn_sched_barrier(0);   // (the compiler would otherwise keep about 12 loads in flight and interleave)
+        for (int j = 0; j < 8; ++j) {
+            const int r = wave + 4 * j;
+            const int gr = min(m0 + r, M - 1);            // rows past M repeat the last row (never stored)
+            dma_piece(rsA, (lane ^ (r & 15)) << 4, lds0 + r * SK_ROWB, (int)(gr * lda * 2));
+        }
+    } else {
+        u32x4 gv[8], uv[8];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) *reinterpret_cast<u32x4*>(sW + sk_off(r0 + 4 * j, ch)) = wv[j];
+        for (int j = 0; j < 8; ++j) {
+            const int gr = min(m0 + wave + 4 * j, M - 1);
+            gv[j] = *reinterpret_cast<const u32x4*>(A + (long)gr * lda + k0 + lane * 8);
+            uv[j] = *reinterpret_cast<const u32x4*>(A + (long)gr * lda + K + k0 + lane * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (all 16 requests before the first use)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        u32x4 v = av[j];
-        if (ASW) {
-            const bf16x8 g = __builtin_bit_cast(bf16x8, av[j]);
+        for (int j = 0; j < 8; ++j) {
+            const bf16x8 g = __builtin_bit_cast(bf16x8, gv[j]);
             const bf16x8 u = __builtin_bit_cast(bf16x8, uv[j]);
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float gf = (float)g[e];
-                const float s = round_bf(gf * __builtin_amdgcn_rcpf(1.f + __expf(-gf)));   // the formula of mgen_swiglu_fwd
-                o[e] = (bf16)(s * (float)u[e]);
+                const float sg = round_bf(gf * __builtin_amdgcn_rcpf(1.f + __expf(-gf)));   // the formula of mgen_swiglu_fwd
+                o[e] = (bf16)(sg * (float)u[e]);
             }
-            v = __builtin_bit_cast(u32x4, o);
+            *reinterpret_cast<bf16x8*>(sA + sk_off(wave + 4 * j, lane)) = o;
         }
-        *reinterpret_cast<u32x4*>(sA + sk_off(r0 + 4 * j, ch)) = v;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- wave (wn, wm): 32 weight rows x 32 token rows; D[n][m] so that a lane ends with 4 consecutive n of one token
-    const int wn = wave & 1, wm = wave >> 1;
-    const int li = lane & 31, g = lane >> 5;
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int rowW = wn * 32 + li, rowA = wm * 32 + li;
+    // ---- wave w: weight rows 16 w .. 16 w + 15 x the 32 token rows; D[n][m]: a lane ends with 4 consecutive n of one
+    // token. A lane supplies 8 reduction indices (one 16-byte chunk) of row (lane & 15) per MFMA.
+    const int r16 = lane & 15, kg = lane >> 4;
+    sk_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int rowW = wave * 16 + r16;
 #pragma unroll 8
-    for (int s = 0; s < SK_KC / 16; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sW + sk_off(rowW, 2 * s + g));
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(sA + sk_off(rowA, 2 * s + g));
-        acc = mfma32(a, b, acc);
+    for (int ks = 0; ks < SK_KC / 32; ++ks) {
+        const int ch = 4 * ks + kg;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sW + sk_off(rowW, ch));
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sA + sk_off(r16, ch));
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sA + sk_off(16 + r16, ch));
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b1, acc1, 0, 0, 0);
     }
-    const int m = m0 + wm * 32 + li;
-    if (m >= M) return;
+    const int n = n0 + wave * 16 + 4 * kg;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 32 + q * 8 + g * 4;
-        if (SLABS) {
-            float* dst = reinterpret_cast<float*>(Cout) + (long)z * slab_stride + (long)m * ldc + n;
-            *reinterpret_cast<f32x4*>(dst) = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        } else {
-            bf16* dst = reinterpret_cast<bf16*>(Cout) + (long)m * ldc + n;
-            const bf16x4 o = {(bf16)acc[4 * q], (bf16)acc[4 * q + 1], (bf16)acc[4 * q + 2], (bf16)acc[4 * q + 3]};
-            *reinterpret_cast<bf16x4*>(dst) = o;
+    for (int mb = 0; mb < 2; ++mb) {
+        const int m = m0 + 16 * mb + r16;
+        const sk_f32x4 acc = mb ? acc1 : acc0;
+        if (m < M) {
+            if (SLABS) {
+                float* dst = reinterpret_cast<float*>(Cout) + (long)z * slab_stride + (long)m * ldc + n;
+                *reinterpret_cast<sk_f32x4*>(dst) = acc;
+            } else {
+                bf16* dst = reinterpret_cast<bf16*>(Cout) + (long)m * ldc + n;
+                const bf16x4 o = {(bf16)acc[0], (bf16)acc[1], (bf16)acc[2], (bf16)acc[3]};
+                *reinterpret_cast<bf16x4*>(dst) = o;
+            }
         }
     }
 }

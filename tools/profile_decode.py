@@ -4,6 +4,8 @@
       prefill + decode of the default decoder (run it under `rocprofv3 --kernel-trace --output-format csv`)
   python tools/profile_decode.py report <kernel_trace.csv>
       per-kernel totals of the launches AFTER the last prefill attention kernel, i.e. of the decode steps only
+  python tools/profile_decode.py timeline <kernel_trace.csv> [launches]
+      the last launches of the run in start order: queue, start (us), duration (us), kernel
 """
 import csv
 import collections
@@ -26,6 +28,21 @@ def run(streams=256, prompt_len=1792, new_tokens=33):
                          seed=1234)
     torch.cuda.synchronize()
     print("generated", tuple(out.shape))
+
+
+def timeline(path, n=260):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    rows = rows[-n:]
+    t0 = int(rows[0]["Start_Timestamp"])
+    short = {"attn_decode": "ATTN", "gemm_skinny_kernelILb1ELb1": "down", "gemm_skinny_kernelILb1ELb0": "o_proj",
+             "gemm_skinny_kernel<true, true>": "down", "gemm_skinny_kernel<true, false>": "o_proj",
+             "gemm_skinny": "qkv|gu", "slab_resid": "slabnorm", "sample": "SAMPLE", "embedding": "embed",
+             "rmsnorm_fwd": "norm", "gemm_kernel": "lm_head"}
+    for r in rows:
+        name = next((v for k, v in short.items() if k in r["Kernel_Name"]), r["Kernel_Name"][:30])
+        b, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+        print(f"q{r.get('Queue_Id', '?'):>3} {b / 1e3:9.1f} {(e - b) / 1e3:7.1f}  {name}")
 
 
 def report(path):
@@ -71,5 +88,7 @@ def report(path):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(*[int(a) for a in sys.argv[2:]])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], *(int(a) for a in sys.argv[3:4]))
     else:
         report(sys.argv[2])
