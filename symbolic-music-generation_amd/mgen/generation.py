@@ -17,6 +17,7 @@ multinomial draw uses explicit Exp(1) noise (argmax p/q): a `noise` tensor [step
 counter-based Philox stream keyed by `seed` (offset = step).
 """
 import os
+import time
 from typing import Optional
 
 import torch
@@ -379,6 +380,7 @@ class GenerationMixin:
                 pt.stream.wait_stream(main)
         n_done = 1
         L = cfg.num_hidden_layers
+        t_issue = time.perf_counter()
         for step in range(1, max_new_tokens):
             if unfinished is not None and step % eos_check_every == 0:
                 if nparts > 1:
@@ -413,6 +415,8 @@ class GenerationMixin:
                         pick(pt.buf.logits, step, pt.b0, pt.b1, pt.buf.next,
                              step_logits[i] if return_step_logits else None)
             n_done = step + 1
+        # host time spent issuing the decode steps (the GPU runs behind): for measurements
+        self.last_decode_issue_s = time.perf_counter() - t_issue
         if nparts > 1:
             for pt in parts:
                 main.wait_stream(pt.stream)

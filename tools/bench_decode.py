@@ -29,5 +29,5 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 1):
         msg.append(f"long context {b['ms_per_step']:.3f} frac {b['hbm_frac']:.4f}")
     if "short" in legs:
         c = bench.bench_decode(model, cfg, 256, 1, 512, dev)
-        msg.append(f"contexts 1-512 {c['ms_per_step']:.3f}")
+        msg.append(f"contexts 1-512 {c['ms_per_step']:.3f} (host issue {model.last_decode_issue_s / 511 * 1e3:.3f} ms/step)")
     print(" | ".join(msg), flush=True)
