@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256, 4) void gemm_skinny_kernel(const bf16* __restr
     char* sW = smem + SK_TM * SK_ROWB;        // weight tile  [64][512] bf16
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * SK_TM, n0 = blockIdx.y * SK_TN, z = blockIdx.z;
+    // the row tiles of one column tile read the same weight rows: they are neighbours in the order that gives the
+    // workgroups of one XCD (one L2) a contiguous range
+    const int mt = (M + SK_TM - 1) / SK_TM;
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (t % mt) * SK_TM, n0 = (t / mt) * SK_TN, z = blockIdx.y;
     const int k0 = z * SK_KC;
     const unsigned lds0 = lds_addr(smem);
 
@@ -136,7 +140,7 @@ int sk_launch(const void* A, const void* W, void* C, int M, int N, int K, long l
         }
         asked[dev] = true;
     }
-    const dim3 grid((M + SK_TM - 1) / SK_TM, N / SK_TN, K / SK_KC), block(256);
+    const dim3 grid(((M + SK_TM - 1) / SK_TM) * (N / SK_TN), K / SK_KC), block(256);
     hipLaunchKernelGGL((gemm_skinny_kernel<SLABS, ASW>), grid, block, SK_LDS, stream, (const bf16*)A, (const bf16*)W, C,
                        M, N, K, lda, ldw, ldc, slab_stride);
     return mgen_check_launch("mgen_gemm_bf16_skinny");
@@ -145,7 +149,7 @@ int sk_launch(const void* A, const void* W, void* C, int M, int N, int K, long l
 }  // namespace
 
 // 1 when mgen_gemm_bf16_skinny takes this product: whole 64-column and 512-index tiles, 16-byte aligned rows, few
-// enough token rows that the operand re-reads of 64 x 64 tiles do not matter, and a bf16 output only without slabs.
+// enough token rows that the operand re-reads of 32 x 64 tiles do not matter, and a bf16 output only without slabs.
 extern "C" int mgen_gemm_skinny_fits(int M, int N, int K, long lda, long ldw, long ldc, int slabs) {
     if (M < 1 || M > 1024 || N < 64 || N % 64 || N > 16384 || K < 512 || K % 512) return 0;
     if (lda % 8 || ldw % 8 || ldc % 4) return 0;
