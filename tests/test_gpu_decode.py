@@ -105,6 +105,43 @@ def test_sampler_matches_reference_warpers(ops, V, dtype):
         assert torch.equal(out.cpu(), ref), (kw, out.cpu().tolist(), ref.tolist())
 
 
+@pytest.mark.parametrize("V", [4096, 151936])
+def test_sampler_wide_key_ranges_masked_and_flat_rows(ops, V):
+    """bf16 rows that stretch the register-resident sampler's histograms: magnitudes from 1e-30 to 1e4 of both signs
+    (more distinct keys than bins: bins of several keys and a second pass), rows with most entries at -inf (masked
+    vocabulary), and a constant row (one key: every token survives, the draw is the smallest noise)."""
+    B = 5
+    g = torch.Generator().manual_seed(V + 1)
+    expo = torch.rand(B, V, generator=g) * 34 - 30               # 10^-30 .. 10^4
+    sign = torch.where(torch.rand(B, V, generator=g) < 0.5, -1.0, 1.0)
+    logits = (sign * 10.0 ** expo).to(torch.bfloat16)
+    logits[1] = (torch.randn(V, generator=g) * 3).to(torch.bfloat16)
+    logits[1, torch.rand(V, generator=g) < 0.9] = float("-inf")  # nine tenths of the vocabulary masked
+    logits[2] = 0.5                                              # constant row
+    logits[3, : V // 2] = float("-inf")
+    noise = torch.empty(B, V).exponential_(1.0, generator=g)
+    ld = (V + 7) // 8 * 8
+    buf = torch.zeros(B, ld, dtype=torch.bfloat16)
+    buf[:, :V] = logits
+    lg, nz = buf.to(dev()), noise.to(dev())
+    out = torch.empty(B, dtype=torch.int64, device=dev())
+    for kw in (dict(temperature=1.0, top_k=0, top_p=0.9), dict(temperature=0.8, top_k=64, top_p=0.95),
+               dict(temperature=1.0, top_k=7, top_p=1.0), dict(temperature=2.0, top_k=0, top_p=0.3)):
+        s = logits.float() / kw["temperature"]
+        warped = R.warp_logits(logits.float(), **kw)
+        # ties at a cut: the kernel keeps the whole group of equal scores (see the test above); top-k ties likewise
+        vmin = torch.where(torch.isfinite(warped), s, torch.full_like(s, float("inf"))).min(-1, keepdim=True).values
+        warped = torch.where(s == vmin, s, warped)
+        ref = R.sample_with_noise(warped, noise)
+        ops.sample(lg, V, out, do_sample=True, noise=nz, **kw)
+        got = out.cpu()
+        assert torch.equal(got, ref), (kw, got.tolist(), ref.tolist())
+        assert bool(torch.isfinite(logits.float()[torch.arange(B), got]).all()), "a masked token was drawn"
+    # the constant row without top-k: everything survives, the draw is the token with the smallest noise
+    ops.sample(lg, V, out, do_sample=True, noise=nz, temperature=1.0, top_k=0, top_p=0.5)
+    assert int(out[2]) == int(noise[2].argmin())
+
+
 def test_sampler_kept_set_matches_reference(ops):
     """The survivor set itself (not only the draw): with noise that favours one index at a time, a token is returned
     iff the reference warpers kept it."""
