@@ -414,6 +414,17 @@ int mgen_sample_rows(const void* logits, long ld, int B, int V, int is_bf16, int
                      int top_k, float top_p, const float* noise, long ld_noise, unsigned long long seed,
                      unsigned long long offset, int row0, long* out, long* out2, long out2_stride,
                      mgen_stream_t stream);
+/* mgen_sample_rows for a decode loop whose launch arguments stay the same from step to step (HIP graph replay):
+ * step (device int, may be null = 0) is added to the Philox offset and to the out2 column when the kernel runs;
+ * unfinished ([B] int64, may be null) carries the EOS bookkeeping of GenerationMixin._sample (TF
+ * generation/utils.py:2919-2931): a finished stream receives pad_id, a stream that draws eos_id is finished from the
+ * next step on. mgen_decode_advance ends such a step: pos[i] += 1, kv_len[i] += 1 for the n streams, step[0] += 1
+ * (the cache positions mgen_attn_decode_prep reads; TF cache_utils.py:127-146 advances them on the host). */
+int mgen_sample_step(const void* logits, long ld, int B, int V, int is_bf16, int do_sample, float temperature,
+                     int top_k, float top_p, const float* noise, long ld_noise, unsigned long long seed,
+                     unsigned long long offset, int row0, long* out, long* out2, long out2_stride, const int* step,
+                     long* unfinished, long eos_id, long pad_id, mgen_stream_t stream);
+int mgen_decode_advance(int* pos, int* kv_len, int n, int* step, mgen_stream_t stream);
 int mgen_philox_exponential(float* out, long ld, int B, int V, unsigned long long seed, unsigned long long offset,
                             mgen_stream_t stream);
 

@@ -57,3 +57,22 @@ extern "C" int mgen_decode_layer(void* x, const float* h_in, float* h_mid, float
     if (int e = mgen_gemm_bf16_skinny(gu, w_down, slabs, B, d, I, 2L * I, I, d, 1, bd, 1, stream)) return e;
     return mgen_slab_resid_rmsnorm(slabs, I / 512, bd, h_mid, h_out, w_next, x, B, d, eps, 1, stream);
 }
+
+namespace {
+__global__ void decode_advance_kernel(int* __restrict__ pos, int* __restrict__ kv_len, int n, int* __restrict__ step) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        pos[i] += 1;
+        kv_len[i] += 1;
+    }
+    if (i == 0 && step) step[0] += 1;
+}
+}  // namespace
+
+// End of a decode step whose launches keep the same arguments at every step (graph replay): every stream's position
+// and key count move on by one, and so does the step counter mgen_sample_step reads.
+extern "C" int mgen_decode_advance(int* pos, int* kv_len, int n, int* step, hipStream_t stream) {
+    MGEN_REQUIRE(pos && kv_len && n > 0, "mgen_decode_advance: bad arguments");
+    hipLaunchKernelGGL(decode_advance_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pos, kv_len, n, step);
+    return mgen_check_launch("mgen_decode_advance");
+}

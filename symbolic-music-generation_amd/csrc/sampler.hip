@@ -106,12 +106,35 @@ struct SampleArgs {
     long* out;
     long* out2; long out2_stride;  // optional second destination: out2[row * out2_stride]
     unsigned row0;                 // Philox row index of logits row 0 (a call on rows [row0, row0 + B) of a larger batch)
+    // decode loops whose launch arguments must not change from step to step (graph replay):
+    const int* step;               // device counter s (or null = 0): Philox offset + s, out2 column + s
+    long* unfinished;              // [B] 1 = stream still generating (or null): finished streams receive pad_id, a stream
+    long eos_id, pad_id;           //     that draws eos_id becomes finished (GenerationMixin._sample's bookkeeping)
 };
+
+// the step counter folded into the arguments (every thread, at the start of a kernel)
+__device__ __forceinline__ void sample_begin(SampleArgs& a) {
+    if (a.step) {
+        const int s = *a.step;
+        a.offset += (unsigned long long)s;
+        if (a.out2) a.out2 += s;
+    }
+}
+// one thread per row: EOS / pad bookkeeping and the stores
+__device__ __forceinline__ void sample_emit(const SampleArgs& a, int row_i, long tok) {
+    if (a.unfinished) {
+        if (a.unfinished[row_i] == 0) tok = a.pad_id;
+        else if (tok == a.eos_id) a.unfinished[row_i] = 0;
+    }
+    a.out[row_i] = tok;
+    if (a.out2) a.out2[(long)row_i * a.out2_stride] = tok;
+}
 
 // ---- generic kernel: one 1024-thread workgroup per row, every pass streams the row from cache ----------------
 template <typename LT>
 __global__ __launch_bounds__(NT) void sample_kernel(SampleArgs a) {
     __shared__ Red red;
+    sample_begin(a);
     const int row_i = blockIdx.x, tid = threadIdx.x, V = a.V;
     const LT* row = reinterpret_cast<const LT*>(a.logits) + (long)row_i * a.ld;
 
@@ -125,8 +148,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(SampleArgs a) {
         best = block_max_u64(best, red);
         if (tid == 0) {
             const long tok = (long)(~(unsigned)best);
-            a.out[row_i] = tok;
-            if (a.out2) a.out2[(long)row_i * a.out2_stride] = tok;
+            sample_emit(a, row_i, tok);
         }
         return;
     }
@@ -227,8 +249,7 @@ __global__ __launch_bounds__(NT) void sample_kernel(SampleArgs a) {
     best = block_max_u64(best, red);
     if (tid == 0) {
         const long tok = (long)(~(unsigned)best);
-        a.out[row_i] = tok;
-        if (a.out2) a.out2[(long)row_i * a.out2_stride] = tok;
+        sample_emit(a, row_i, tok);
     }
 }
 
@@ -282,6 +303,7 @@ __global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
     constexpr int NW = FNT / 64;
     __shared__ Red red;
     extern __shared__ __attribute__((aligned(16))) unsigned long long hist[];
+    sample_begin(a);
     const int row_i = blockIdx.x, tid = threadIdx.x, V = a.V;
     const unsigned short* row = reinterpret_cast<const unsigned short*>(a.logits) + (long)row_i * a.ld;
 
@@ -320,8 +342,7 @@ __global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
         best = block_max_u64<NW>(best, red);
         if (tid == 0) {
             const long tok = (long)(~(unsigned)best);
-            a.out[row_i] = tok;
-            if (a.out2) a.out2[(long)row_i * a.out2_stride] = tok;
+            sample_emit(a, row_i, tok);
         }
         return;
     }
@@ -536,8 +557,7 @@ __global__ __launch_bounds__(FNT) void sample_bf16_kernel(SampleArgs a) {
     best = block_max_u64<NW>(best, red);
     if (tid == 0) {
         const long tok = (long)(~(unsigned)best);
-        a.out[row_i] = tok;
-        if (a.out2) a.out2[(long)row_i * a.out2_stride] = tok;
+        sample_emit(a, row_i, tok);
     }
 }
 
@@ -552,15 +572,15 @@ __global__ void philox_exp_kernel(float* __restrict__ out, long ld, int B, int V
 
 }  // namespace
 
-// logits [B][ld] (bf16 or fp32) -> out[B] int64. do_sample = 0: argmax. Otherwise temperature > 0, top_k (0 = off),
-// top_p in (0, 1] (1 = off); noise [B][ld_noise] fp32 Exp(1) draws, or null to use Philox(seed, offset).
-// out2 (may be null) receives the same ids at out2[b * out2_stride] (a column of the generated-sequence matrix).
-// row0: the rows are rows [row0, row0 + B) of a larger batch; the Philox stream of row i is that of row row0 + i of
-// one call on the whole batch (explicit noise is indexed from the pointer given).
-extern "C" int mgen_sample_rows(const void* logits, long ld, int B, int V, int is_bf16, int do_sample,
+// mgen_sample_rows for a decode loop: step (device int, may be null) is added to the Philox offset and to the out2
+// column at run time, so the launch arguments are the same at every step; unfinished ([B] int64, may be null) carries
+// the EOS bookkeeping of GenerationMixin._sample (generation/utils.py:2919-2931): a finished stream receives pad_id,
+// a stream that draws eos_id is finished from the next step on.
+extern "C" int mgen_sample_step(const void* logits, long ld, int B, int V, int is_bf16, int do_sample,
                                 float temperature, int top_k, float top_p, const float* noise, long ld_noise,
                                 unsigned long long seed, unsigned long long offset, int row0, long* out, long* out2,
-                                long out2_stride, hipStream_t stream) {
+                                long out2_stride, const int* step, long* unfinished, long eos_id, long pad_id,
+                                hipStream_t stream) {
     MGEN_REQUIRE(logits && out && B > 0 && V > 0 && ld >= V && row0 >= 0, "mgen_sample: bad arguments");
     if (do_sample) {
         MGEN_REQUIRE(temperature > 0.f, "mgen_sample: `temperature` (=%g) has to be a strictly positive float", temperature);
@@ -572,6 +592,7 @@ extern "C" int mgen_sample_rows(const void* logits, long ld, int B, int V, int i
     a.logits = logits; a.ld = ld; a.V = V; a.temperature = temperature; a.top_k = top_k; a.top_p = top_p;
     a.do_sample = do_sample; a.noise = noise; a.ld_noise = ld_noise; a.seed = seed; a.offset = offset; a.out = out;
     a.out2 = out2; a.out2_stride = out2_stride; a.row0 = (unsigned)row0;
+    a.step = step; a.unfinished = unfinished; a.eos_id = eos_id; a.pad_id = pad_id;
     const bool fast = is_bf16 && V <= FAST_MAX_V && ld % 8 == 0 && ((uintptr_t)logits % 16) == 0;
     if (fast) {
         constexpr int lds = SAMPLE_HB * 8;
@@ -592,6 +613,19 @@ extern "C" int mgen_sample_rows(const void* logits, long ld, int B, int V, int i
     else if (is_bf16) hipLaunchKernelGGL((sample_kernel<bf16>), dim3(B), dim3(NT), 0, stream, a);
     else hipLaunchKernelGGL((sample_kernel<float>), dim3(B), dim3(NT), 0, stream, a);
     return mgen_check_launch("mgen_sample");
+}
+
+// logits [B][ld] (bf16 or fp32) -> out[B] int64. do_sample = 0: argmax. Otherwise temperature > 0, top_k (0 = off),
+// top_p in (0, 1] (1 = off); noise [B][ld_noise] fp32 Exp(1) draws, or null to use Philox(seed, offset).
+// out2 (may be null) receives the same ids at out2[b * out2_stride] (a column of the generated-sequence matrix).
+// row0: the rows are rows [row0, row0 + B) of a larger batch; the Philox stream of row i is that of row row0 + i of
+// one call on the whole batch (explicit noise is indexed from the pointer given).
+extern "C" int mgen_sample_rows(const void* logits, long ld, int B, int V, int is_bf16, int do_sample,
+                                float temperature, int top_k, float top_p, const float* noise, long ld_noise,
+                                unsigned long long seed, unsigned long long offset, int row0, long* out, long* out2,
+                                long out2_stride, hipStream_t stream) {
+    return mgen_sample_step(logits, ld, B, V, is_bf16, do_sample, temperature, top_k, top_p, noise, ld_noise, seed,
+                            offset, row0, out, out2, out2_stride, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int mgen_sample(const void* logits, long ld, int B, int V, int is_bf16, int do_sample, float temperature,

@@ -93,6 +93,8 @@ SIGNATURES = {
     "mgen_attn_decode_prep": [P, L, P, P, P, P, F, I, P, P, P, P, L, P, I, I, I, I, I, I, F, P],
     "mgen_sample_rows": [P, L, I, I, I, I, F, I, F, P, L, U64, U64, I, P, P, L, P],
     "mgen_sample": [P, L, I, I, I, I, F, I, F, P, L, U64, U64, P, P, L, P],
+    "mgen_sample_step": [P, L, I, I, I, I, F, I, F, P, L, U64, U64, I, P, P, L, P, P, L, L, P],
+    "mgen_decode_advance": [P, P, I, P, P],
     "mgen_philox_exponential": [P, L, I, I, U64, U64, P],
 }
 

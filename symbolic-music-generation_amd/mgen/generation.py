@@ -67,6 +67,11 @@ class _Part:
 _TWO_PART_MIN_STREAMS = 64
 # MGEN_DECODE_LAYER_C=0: issue the launches of a decode layer one by one from Python (for measurements)
 _LAYER_IN_ONE_CALL = os.environ.get("MGEN_DECODE_LAYER_C", "1") != "0"
+# MGEN_DECODE_GRAPH=1: replay every decode step from a captured HIP graph instead of issuing its launches one by one.
+# Off by default: on this ROCm the replay of the ~200 kernel nodes of a two-part step costs the host as much as the
+# launches themselves (1.31 against 1.25 ms per step) and the per-step join of the two parts costs the GPU time
+# (contexts 1792-2048: 4.83 against 4.53 ms per step).
+_DECODE_GRAPH = os.environ.get("MGEN_DECODE_GRAPH", "0") == "1"
 
 
 class _DecodeBuffers:
@@ -146,8 +151,11 @@ class GenerationMixin:
         eps = cfg.rms_norm_eps
         L = cfg.num_hidden_layers
         v = self._layers[l]
-        pos = lens[t]          # int32 [>= B] = t
-        kv_len = lens[t + 1]   # int32 [>= B] = t + 1
+        if isinstance(lens, tuple):
+            pos, kv_len = lens     # live buffers a launch at the end of the step moves on (graph replay)
+        else:
+            pos = lens[t]          # int32 [>= B] = t
+            kv_len = lens[t + 1]   # int32 [>= B] = t + 1
         h = buf.h
         if _LAYER_IN_ONE_CALL and buf.sk_qkv and buf.sk_gu and buf.sk_o and buf.sk_down and not self._ln:
             # every launch of the layer issued by one library call (the pointer arguments are collected once per
@@ -348,20 +356,19 @@ class GenerationMixin:
         unfinished = torch.ones(B, dtype=torch.int64, device=dev) if eos_token_id is not None else None
         step_logits = [[] for _ in parts] if return_step_logits else None
 
-        def pick(logits, step, b0, b1, nxt, log=None):
-            """Rows [b0, b1) of the batch: choose the token of generation step `step` from their logits."""
+        def pick(logits, step, b0, b1, nxt, log=None, step_dev=None):
+            """Rows [b0, b1) of the batch: choose the token of generation step `step` from their logits (step_dev: the
+            step is read from this device counter when the launch runs, `step` is then ignored)."""
             nz = noise[step][b0:b1] if (noise is not None and do_sample) else None
-            col = out.data_ptr() + 8 * (b0 * total + P + step)
-            ops.sample(logits, V, nxt, do_sample, temperature, top_k or 0, top_p, nz, seed, step,
-                       out2=None if unfinished is not None else col, out2_stride=total, row0=b0)
+            first_col = P if step_dev is not None else P + step
+            col = out.data_ptr() + 8 * (b0 * total + first_col)
+            ops.sample(logits, V, nxt, do_sample, temperature, top_k or 0, top_p, nz, seed,
+                       0 if step_dev is not None else step, out2=col, out2_stride=total, row0=b0, step=step_dev,
+                       unfinished=unfinished[b0:b1] if unfinished is not None else None,
+                       eos_id=eos_token_id if unfinished is not None else 0,
+                       pad_id=pad_token_id if unfinished is not None else 0)
             if log is not None:
                 log.append(logits[:, :V].float().clone())
-            if unfinished is not None:
-                unf = unfinished[b0:b1]
-                tok = nxt * unf + pad_token_id * (1 - unf)
-                nxt.copy_(tok)
-                out[b0:b1, P + step] = tok
-                unf.mul_((tok != eos_token_id).long())
 
         # ---- prefill: the training forward on the prompt, K/V written into the cache
         xN, _ = self._run_layers(prompt.contiguous(), save=None, cache=cache)
@@ -381,6 +388,53 @@ class GenerationMixin:
         n_done = 1
         L = cfg.num_hidden_layers
         t_issue = time.perf_counter()
+
+        def issue_step(step, t, live):
+            """The launches of one decode step: every part's layers, lm_head and token choice. live: positions and
+            step index come from device buffers that the last launch of the step moves on, so the same launches serve
+            every step (what a captured graph replays); otherwise they are arguments of this step's launches."""
+            if nparts == 1:
+                pt = parts[0]
+                logits = self._decode_step(pt.buf.next, pt.cache, t, pt.buf, pt.live if live else pt.lens, pt.ws)
+                pick(logits, step, 0, B, pt.buf.next, step_logits[0] if return_step_logits else None,
+                     pt.step_dev if live else None)
+                if live:
+                    ops.decode_advance(pt.live[0], pt.live[1], pt.step_dev)
+                return
+            # The launches of the two halves are issued layer by layer in turn, each half on its own stream.
+            # (Chaining the attention launches of the two halves through events, so that they never run at the
+            # same time, measured slower than leaving the two streams alone: 5.68 against 5.45 ms per step.)
+            try:
+                for pt in parts:
+                    ops.use_stream(pt.stream.cuda_stream)
+                    self._decode_begin(pt.buf.next, pt.buf)
+                for l in range(L):
+                    for pt in parts:
+                        ops.use_stream(pt.stream.cuda_stream)
+                        self._decode_layer(l, pt.cache, t, pt.buf, pt.live if live else pt.lens, pt.ws)
+                for pt in parts:
+                    ops.use_stream(pt.stream.cuda_stream)
+                    self._decode_end(pt.buf)
+            finally:
+                ops.use_stream(None)
+            for i, pt in enumerate(parts):
+                with torch.cuda.stream(pt.stream):
+                    pick(pt.buf.logits, step, pt.b0, pt.b1, pt.buf.next,
+                         step_logits[i] if return_step_logits else None, pt.step_dev if live else None)
+                    if live:
+                        ops.decode_advance(pt.live[0], pt.live[1], pt.step_dev)
+
+        # A decode step as a HIP graph (opt-in, see _DECODE_GRAPH): the step's launches are captured once (per
+        # attention split count) with positions and step index in device buffers, and replayed.
+        graphs = None
+        if (_DECODE_GRAPH and max_new_tokens > 3 and noise is None and not return_step_logits
+                and type(self)._decode_step is GenerationMixin._decode_step and not self._ln
+                and all(pt.buf.sk_qkv and pt.buf.sk_gu and pt.buf.sk_o and pt.buf.sk_down for pt in parts)):
+            graphs = {}
+            for pt in parts:
+                pt.live = (pt.lens[P].clone(), pt.lens[P + 1].clone())      # positions / key counts of step 1
+                pt.step_dev = torch.ones(1, dtype=torch.int32, device=dev)  # generation step of the next launch
+            cap_stream = torch.cuda.Stream(device=dev)
         for step in range(1, max_new_tokens):
             if unfinished is not None and step % eos_check_every == 0:
                 if nparts > 1:
@@ -389,31 +443,27 @@ class GenerationMixin:
                 if int(unfinished.max()) == 0:
                     break
             t = P + step - 1
-            if nparts == 1:
-                pt = parts[0]
-                logits = self._decode_step(pt.buf.next, pt.cache, t, pt.buf, pt.lens, pt.ws)
-                pick(logits, step, 0, B, pt.buf.next, step_logits[0] if return_step_logits else None)
+            if graphs is None:
+                issue_step(step, t, False)
+            elif step == 1:
+                issue_step(step, t, True)    # (not captured: the first launches of a process set kernel attributes)
+                if nparts > 1:
+                    for pt in parts:
+                        main.wait_stream(pt.stream)
             else:
-                # The launches of the two halves are issued layer by layer in turn, each half on its own stream.
-                # (Chaining the attention launches of the two halves through events, so that they never run at the
-                # same time, measured slower than leaving the two streams alone: 5.68 against 5.45 ms per step.)
-                try:
-                    for pt in parts:
-                        ops.use_stream(pt.stream.cuda_stream)
-                        self._decode_begin(pt.buf.next, pt.buf)
-                    for l in range(L):
-                        for pt in parts:
-                            ops.use_stream(pt.stream.cuda_stream)
-                            self._decode_layer(l, pt.cache, t, pt.buf, pt.lens, pt.ws)
-                    for pt in parts:
-                        ops.use_stream(pt.stream.cuda_stream)
-                        self._decode_end(pt.buf)
-                finally:
-                    ops.use_stream(None)
-                for i, pt in enumerate(parts):
-                    with torch.cuda.stream(pt.stream):
-                        pick(pt.buf.logits, step, pt.b0, pt.b1, pt.buf.next,
-                             step_logits[i] if return_step_logits else None)
+                key = tuple(self._decode_split(pt.b1 - pt.b0, t + 1) for pt in parts)
+                g = graphs.get(key)
+                if g is None:
+                    g = graphs[key] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=cap_stream):
+                        if nparts > 1:
+                            for pt in parts:
+                                pt.stream.wait_stream(cap_stream)
+                        issue_step(step, t, True)
+                        if nparts > 1:
+                            for pt in parts:
+                                cap_stream.wait_stream(pt.stream)
+                g.replay()
             n_done = step + 1
         # host time spent issuing the decode steps (the GPU runs behind): for measurements
         self.last_decode_issue_s = time.perf_counter() - t_issue

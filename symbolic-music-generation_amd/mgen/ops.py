@@ -581,13 +581,21 @@ def attn_decode_workspace(B, H, D, nsplit):
 
 
 def sample(logits, V, out, do_sample=False, temperature=1.0, top_k=0, top_p=1.0, noise=None, seed=0, offset=0,
-           out2=None, out2_stride=0, row0=0):
+           out2=None, out2_stride=0, row0=0, step=None, unfinished=None, eos_id=0, pad_id=0):
     """logits [B, ld] (bf16 or fp32) -> out [B] int64; out2 = raw pointer of an optional strided second destination.
-    row0: the rows are rows [row0, row0 + B) of a larger batch (Philox stream of row i = that of row row0 + i)."""
+    row0: the rows are rows [row0, row0 + B) of a larger batch (Philox stream of row i = that of row row0 + i).
+    step (int32 device tensor): added to `offset` and to the out2 column when the kernel runs; unfinished ([B] int64
+    device tensor): finished streams receive pad_id, a stream that draws eos_id becomes finished."""
     B = logits.shape[0]
-    call("mgen_sample_rows", _p(logits), logits.stride(0), B, V, int(logits.dtype == torch.bfloat16), int(do_sample),
+    call("mgen_sample_step", _p(logits), logits.stride(0), B, V, int(logits.dtype == torch.bfloat16), int(do_sample),
          float(temperature), int(top_k or 0), float(top_p), _p(noise), noise.stride(0) if noise is not None else 0,
-         int(seed), int(offset), int(row0), _p(out), out2 or 0, out2_stride, _stream())
+         int(seed), int(offset), int(row0), _p(out), out2 or 0, out2_stride, _p(step), _p(unfinished), int(eos_id),
+         int(pad_id), _stream())
+
+
+def decode_advance(pos, kv_len, step):
+    """pos += 1, kv_len += 1 (int32 device tensors of one entry per stream), step[0] += 1."""
+    call("mgen_decode_advance", _p(pos), _p(kv_len), pos.numel(), _p(step), _stream())
 
 
 def decode_qkv_prep(qkv, ld_in, qout, ld_q, k_cache, v_cache, wq, wk, cs, pos, B, HQ, HK, D, max_len, eps,

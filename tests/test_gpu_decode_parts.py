@@ -106,3 +106,31 @@ def test_reserved_kv_cache_gives_the_same_tokens(model):
         finally:
             model.release_kv_cache()
     assert model._kv_reserved is None
+
+
+@pytest.mark.parametrize("B", [2, 70])
+def test_graph_replay_equals_launch_by_launch(model, B, monkeypatch):
+    """Decode steps replayed from a captured HIP graph (positions, step index and EOS state in device buffers) give the
+    tokens of the launch-by-launch loop: greedy, Philox sampling, EOS / pad bookkeeping with early stop, left-padded
+    prompts, and a run long enough for the attention split count (hence the captured graph) to change."""
+    from mgen import generation
+    g = torch.Generator().manual_seed(40 + B)
+    prompt = torch.randint(3, 2048, (B, 6), generator=g).cuda()
+    mask = torch.ones(B, 6, dtype=torch.long)
+    mask[1, :4] = 0
+    mask = mask.cuda()
+    free = model.generate(prompt, max_new_tokens=30, do_sample=True, top_k=0, top_p=0.9, seed=9)
+    eos = int(free[0, 6 + 9])
+    runs = [dict(max_new_tokens=40, do_sample=False),
+            dict(max_new_tokens=40, do_sample=True, temperature=0.9, top_k=0, top_p=0.9, seed=9),
+            dict(max_new_tokens=40, do_sample=True, top_k=0, top_p=0.9, seed=9, eos_token_id=eos, pad_token_id=0,
+                 eos_check_every=4),
+            dict(max_new_tokens=40, do_sample=True, top_k=20, top_p=0.9, seed=3, attention_mask=mask),
+            dict(max_new_tokens=600 if B == 2 else 8, do_sample=False)]
+    monkeypatch.setattr(generation, "_DECODE_GRAPH", True)
+    with_graph = [model.generate(prompt, **kw) for kw in runs]
+    monkeypatch.setattr(generation, "_DECODE_GRAPH", False)
+    without = [model.generate(prompt, **kw) for kw in runs]
+    for kw, a, b in zip(runs, with_graph, without):
+        assert a.shape == b.shape and torch.equal(a, b), kw
+    assert with_graph[2].shape[1] <= 6 + 40
