@@ -239,8 +239,8 @@ class GenerationMixin:
         ones per token, position ids count real tokens only). Each stream then produces what it would produce alone
         from its unpadded prompt: internally the rows are shifted to start at column 0, the prefill runs on the shifted
         batch (causal attention keeps the tail a shorter row carries out of its real tokens' sight) and every stream
-        decodes at its own position. Right padding in generate() is refused (the reference library would continue such a row
-        from a padding token)."""
+        decodes at its own position. Right padding in generate() is refused (the reference library would continue
+        such a row from a padding token)."""
         if input_ids is None or input_ids.dim() != 2:
             raise ValueError("generate() needs input_ids of shape [batch, prompt_len]")
         if not input_ids.is_cuda:
