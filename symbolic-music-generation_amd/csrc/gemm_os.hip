@@ -517,9 +517,10 @@ bool mgen_gemm_os_fits(int M, int N, int K, long lda, long ldb, long ldc, long l
     }
     // the products with few output columns: whole 256-row tiles (rows beyond the operand would be read), at least as
     // many tiles as CUs
-    // (input gradients up to MGEN_GEMM_OS_NMAX output columns, default 2048: the column tiles of a row panel are
-    // neighbours in the XCD-aware order and share the panel's rows in L2)
-    static const int nmax = [] { const char* v = getenv("MGEN_GEMM_OS_NMAX"); return v ? atoi(v) : 2048; }();
+    // (input gradients up to MGEN_GEMM_OS_NMAX output columns, default 8192: the column tiles of a row panel are
+    // neighbours in the XCD-aware order and share the panel's rows in L2; the 650M model's down-projection input
+    // gradient, 32 768 x 6144 x 1536, runs 1.2 times faster here than on the tile loop)
+    static const int nmax = [] { const char* v = getenv("MGEN_GEMM_OS_NMAX"); return v ? atoi(v) : 8192; }();
     if (M % 256 != 0 || N % 256 != 0 || N > (dgrad ? nmax : 1024) || (long)(M / 256) * (N / 256) < 256) return false;
     if ((ldc % 8) || (proj && ((ldc % 4) || (ldr % 4)))) return false;
     if (256L * lda * 2 >= (1L << 32)) return false;
