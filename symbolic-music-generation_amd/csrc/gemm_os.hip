@@ -494,6 +494,30 @@ int os_launch(const OsArgs& g, hipStream_t stream) {
 
 }  // namespace
 
+// Number of reduction slices of a product that is added to its output. Fewer tiles than CUs: as many slices as fill one
+// round of workgroups. More: the count (at most 4) that leaves the least of the last round of workgroups empty - 576
+// tiles (the four weight gradients of a layer of the 650M model) are 2.25 rounds on 256 CUs, i.e. 3; in 4 slices they
+// are 9 full rounds. Slices keep at least 1024 reduction indices.
+static int os_pick_slices(int tiles, int steps, bool many_ok) {
+    const int maxsk = steps / 32 > 1 ? steps / 32 : 1;
+    if (tiles < 256) {
+        const int sk = 256 / tiles;
+        return sk > maxsk ? maxsk : sk;
+    }
+    if (!many_ok) return 1;
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sk = 1; sk <= 4 && sk <= maxsk; ++sk) {
+        const double r = (double)tiles * sk / 256.0;
+        const double eff = r / (double)(long)(r + 0.999999);
+        if (eff > best_eff + 0.03) {   // (more slices are more atomics: only for a real gain)
+            best_eff = eff;
+            best = sk;
+        }
+    }
+    return best;
+}
+
 bool mgen_gemm_os_fits(int M, int N, int K, long lda, long ldb, long ldc, long ldr, int transA, int transB,
                        int out_mode) {
     const char* e = getenv("MGEN_GEMM_OS");   // MGEN_GEMM_OS=0: never (same-process A/B runs)
@@ -539,11 +563,9 @@ int mgen_gemm_os_launch(const void* A, const void* B, void* C, const void* resid
     const int tiles = g.nbm * g.nbn;
     const int steps = K / OS_BK;
     int sk = 1;
-    if (out_mode == OS_OUT_F32_ACC && tiles < 256) {
-        sk = 256 / tiles;
-        const int maxsk = steps / 32;
-        if (sk > maxsk) sk = maxsk;
-        if (sk < 1) sk = 1;
+    if (out_mode == OS_OUT_F32_ACC) {
+        static const bool many = [] { const char* v = getenv("MGEN_GEMM_OS_SK_MANY"); return v && v[0] == '1'; }();
+        sk = os_pick_slices(tiles, steps, many);
     }
     if (out_mode == OS_OUT_F32_ACC) {
         // and at least as many slices as keep a slice of either operand below 4 GiB (32-bit buffer offsets)
@@ -606,10 +628,8 @@ extern "C" int mgen_gemm_bf16_wgrad_group(int n, const void* const* A, const voi
     }
     for (int i = n; i <= OS_GROUP_MAX; ++i) gg.first_tile[i] = tiles;
     const int steps = K / OS_BK;
-    int sk = tiles < 256 ? 256 / tiles : 1;
-    const int maxsk = steps / 32;
-    if (sk > maxsk) sk = maxsk;
-    if (sk < 1) sk = 1;
+    static const bool many = [] { const char* v = getenv("MGEN_GEMM_OS_SK_MANY"); return !(v && v[0] == '0'); }();
+    int sk = os_pick_slices(tiles, steps, many);
     {   // at least as many slices as keep a slice of the widest operand below 4 GiB (32-bit buffer offsets)
         long ldmax = 8;
         for (int i = 0; i < n; ++i) ldmax = lda[i] > ldmax ? lda[i] : (ldb[i] > ldmax ? ldb[i] : ldmax);
