@@ -507,7 +507,8 @@ static int os_pick_slices(int tiles, int steps, bool many_ok) {
     if (!many_ok) return 1;
     int best = 1;
     double best_eff = 0.0;
-    for (int sk = 1; sk <= 4 && sk <= maxsk; ++sk) {
+    const int maxmany = steps / 192;   // (slices of at least 6144 indices here: 4 slices of 4096 measured a loss)
+    for (int sk = 1; sk <= 4 && sk <= maxsk && (sk == 1 || sk <= maxmany); ++sk) {
         const double r = (double)tiles * sk / 256.0;
         const double eff = r / (double)(long)(r + 0.999999);
         if (eff > best_eff + 0.03) {   // (more slices are more atomics: only for a real gain)
