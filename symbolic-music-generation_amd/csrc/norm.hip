@@ -184,8 +184,18 @@ __global__ __launch_bounds__(1024) void rmsnorm_dw_reduce_kernel(float* __restri
     const int col = blockIdx.x * 64 + lane;
     const float* rows = g_dw_rows + (long)slot * NORM_DW_MAXB * 2048;
     float s = 0.f;
-    if (col < d)
-        for (int b = g; b < nblocks; b += 16) s += rows[(long)b * 2048 + col];
+    if (col < d) {
+        // eight rows requested before the first is added (one load after the other is 32 cache round trips in a row)
+        int b = g;
+        for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = rows[(long)(b + 16 * k) * 2048 + col];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; b < nblocks; b += 16) s += rows[(long)b * 2048 + col];
+    }
     part[g][lane] = s;
     __syncthreads();
     if (g == 0 && col < d) {
