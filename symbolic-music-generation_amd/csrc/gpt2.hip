@@ -8,6 +8,7 @@
 // output is rounded at the next GEMM input; the activation is evaluated in fp32 from the bf16 GEMM output (pow is an
 // fp32 autocast op) and rounded at the next GEMM input.
 #include "common.h"
+#include "dw_rows.h"
 
 namespace {
 
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ dres,
                                                             DyT* __restrict__ dres_lp, float* __restrict__ dw,
-                                                            float* __restrict__ db, long T, int d, int accumulate) {
+                                                            float* __restrict__ db, long T, int d, int accumulate,
+                                                            float* __restrict__ rows) {
     __shared__ float red[4 * 256 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long wave0 = (long)blockIdx.x * 4 + wave;
@@ -140,8 +142,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const DyT* __restric
                 f32x4 s = *reinterpret_cast<f32x4*>(&red[lane * 4]);
                 for (int k = 1; k < 4; ++k) s += *reinterpret_cast<f32x4*>(&red[(k * 64 + lane) * 4]);
                 const int c = (i * 64 + lane) * 4;
-                if (c < d)
-                    for (int e = 0; e < 4; ++e) atomicAdd((which ? db : dw) + c + e, s[e]);
+                if (c < d) {
+                    // the block's partial row: [dw | db] in its row of the stream's set (summed by a second launch),
+                    // or, without a set, atomics straight into the gradients
+                    if (rows) *reinterpret_cast<f32x4*>(rows + (long)blockIdx.x * MGEN_DW_ROW + which * d + c) = s;
+                    else
+                        for (int e = 0; e < 4; ++e) atomicAdd((which ? db : dw) + c + e, s[e]);
+                }
             }
         }
 }
@@ -180,9 +187,10 @@ __global__ __launch_bounds__(256) void gelu_kernel(const bf16* __restrict__ h, c
 }
 
 // out[n] (+)= sum_t x[t][n]  (x bf16 [T][ld], n < N, N % 8 == 0). Block = 256 threads = 32 column groups of 8 x 8 row
-// lanes; each block reduces a strip of rows and adds its partial with atomics.
+// lanes; each block reduces a strip of rows and leaves its partial in the strip's row of the stream's set of partial
+// rows (or, without a set, adds it with atomics).
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, long ld, float* __restrict__ out,
-                                                     long T, int N, long rows_per_block) {
+                                                     long T, int N, long rows_per_block, float* __restrict__ rows) {
     __shared__ float red[8][32][8];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int n = (blockIdx.x * 32 + cg) * 8;
@@ -203,7 +211,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
         for (int e = 0; e < 8; ++e) {
             float a = 0.f;
             for (int k = 0; k < 8; ++k) a += red[k][cg][e];
-            atomicAdd(out + n + e, a);
+            if (rows) rows[(long)blockIdx.y * MGEN_DW_ROW + n + e] = a;   // the strip's partial row (summed afterwards)
+            else atomicAdd(out + n + e, a);
         }
     }
 }
@@ -260,14 +269,21 @@ extern "C" int mgen_layernorm_bwd(const void* dy, const float* x, const float* w
     MGEN_REQUIRE(dy && x && w && mean && rstd && dres && dw && db, "mgen_layernorm_bwd: null pointer");
     MGEN_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && d <= 2048, "mgen_layernorm_bwd: need 0<d<=2048, d%%4==0 (d=%d)", d);
     const dim3 grid(ln_grid(T, 512)), block(256);
+    static_assert(512 <= MGEN_DW_MAXB, "a launch's workgroups need a partial row each");
+    const int slot = 2 * d <= MGEN_DW_ROW ? mgen_dw_slot(stream) : -1;
+    float* rows = mgen_dw_rows(slot);
     DISPATCH_VPL(d, {
         if (dy_bf16)
             hipLaunchKernelGGL((layernorm_bwd_kernel<VPL, bf16>), grid, block, 0, stream, (const bf16*)dy, x, w, mean,
-                               rstd, dres, (bf16*)dres_lp, dw, db, T, d, accumulate);
+                               rstd, dres, (bf16*)dres_lp, dw, db, T, d, accumulate, rows);
         else
             hipLaunchKernelGGL((layernorm_bwd_kernel<VPL, float>), grid, block, 0, stream, (const float*)dy, x, w,
-                               mean, rstd, dres, (float*)dres_lp, dw, db, T, d, accumulate);
+                               mean, rstd, dres, (float*)dres_lp, dw, db, T, d, accumulate, rows);
     });
+    if (rows) {
+        mgen_dw_reduce(dw, d, (int)grid.x, slot, 0, stream);
+        mgen_dw_reduce(db, d, (int)grid.x, slot, d, stream);
+    }
     return mgen_check_launch("mgen_layernorm_bwd");
 }
 
@@ -311,6 +327,10 @@ extern "C" int mgen_colsum_bf16(const void* x, long ld, float* out, long T, int 
     long rows = (T + gy - 1) / gy;
     if (rows < 64) rows = 64;
     gy = (T + rows - 1) / rows;
-    hipLaunchKernelGGL(colsum_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, stream, (const bf16*)x, ld, out, T, N, rows);
+    const int slot = (N <= MGEN_DW_ROW && gy <= MGEN_DW_MAXB) ? mgen_dw_slot(stream) : -1;
+    float* part = mgen_dw_rows(slot);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, stream, (const bf16*)x, ld, out, T, N, rows,
+                       part);
+    if (part) mgen_dw_reduce(out, N, (int)gy, slot, 0, stream);
     return mgen_check_launch("mgen_colsum_bf16");
 }

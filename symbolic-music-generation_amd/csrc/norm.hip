@@ -10,6 +10,7 @@
 // dx is added into the fp32 gradient of the residual stream (the norm sits on a residual branch) and the updated
 // gradient is also emitted in the GEMM input dtype for the next dgrad/wgrad.
 #include "common.h"
+#include "dw_rows.h"
 #include <map>
 #include <mutex>
 #include <utility>
@@ -85,12 +86,9 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 // at 768 x 1536.) The array holds NORM_DW_SLOTS such sets of rows: the entry point gives every (device, stream) pair a
 // set of its own, so launches that overlap on one GPU (different streams) never share one, and launches on one stream
 // are ordered. A stream that finds every set taken runs the DIRECT form (atomics straight into dw: no shared state).
-#ifndef MGEN_NORM_DW_MAXB
-#define MGEN_NORM_DW_MAXB 512
-#endif
-constexpr int NORM_DW_MAXB = MGEN_NORM_DW_MAXB;   // workgroups per launch at most
+constexpr int NORM_DW_MAXB = MGEN_DW_MAXB;   // workgroups per launch at most
 constexpr int NORM_DW_SLOTS = 8;
-static __device__ float g_dw_rows[(long)NORM_DW_SLOTS * NORM_DW_MAXB * 2048];
+static __device__ float g_dw_rows[(long)NORM_DW_SLOTS * NORM_DW_MAXB * MGEN_DW_ROW];
 
 // Workgroups of 16 waves, one per CU (16 waves for rows of up to 512 elements; 4 for longer rows, whose per-lane
 // state needs more than 128 VGPRs).
@@ -178,11 +176,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void rmsnorm_bwd_kernel(const DyT* 
 }
 
 // dw[col] += sum over the nblocks rows of the slot's set; one workgroup of 16 waves per 64 columns
-__global__ __launch_bounds__(1024) void rmsnorm_dw_reduce_kernel(float* __restrict__ dw, int d, int nblocks, int slot) {
+__global__ __launch_bounds__(1024) void rmsnorm_dw_reduce_kernel(float* __restrict__ dw, int d, int nblocks, int slot,
+                                                                 int col0) {
     __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
-    const float* rows = g_dw_rows + (long)slot * NORM_DW_MAXB * 2048;
+    const float* rows = g_dw_rows + (long)slot * NORM_DW_MAXB * 2048 + col0;
     float s = 0.f;
     if (col < d) {
         // eight rows requested before the first is added (one load after the other is 32 cache round trips in a row)
@@ -236,7 +235,7 @@ void launch_rmsnorm_bwd(hipStream_t stream, int slot, const void* dy, const floa
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, DyT, false>), grid, block, 0, stream, (const DyT*)dy, x, w, rstd,
                            dres, (DyT*)dres_lp, dw, T, d, accumulate, slot);
         hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, dim3((d + 63) / 64), dim3(1024), 0, stream, dw, d, (int)grid.x,
-                           slot);
+                           slot, 0);
     } else
         hipLaunchKernelGGL((rmsnorm_bwd_kernel<VPL, DyT, true>), grid, block, 0, stream, (const DyT*)dy, x, w, rstd,
                            dres, (DyT*)dres_lp, dw, T, d, accumulate, 0);
@@ -248,6 +247,26 @@ inline int norm_grid(long T) {
 }
 
 }  // namespace
+
+int mgen_dw_slot(hipStream_t stream) { return norm_dw_slot(stream); }
+
+float* mgen_dw_rows(int slot) {
+    static float* base[16] = {};
+    int dev = 0;
+    if (slot < 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!base[dev]) {   // (in host code the array's name is a stand-in: only hipGetSymbolAddress yields the address)
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_dw_rows)) != hipSuccess) return nullptr;
+        base[dev] = reinterpret_cast<float*>(p);
+    }
+    return base[dev] + (long)slot * NORM_DW_MAXB * MGEN_DW_ROW;
+}
+
+void mgen_dw_reduce(float* dst, int n, int nblocks, int slot, int col0, hipStream_t stream) {
+    hipLaunchKernelGGL(rmsnorm_dw_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, stream, dst, n, nblocks, slot,
+                       col0);
+}
+
 
 #define DISPATCH_VPL(d, CALL)                                                             \
     if ((d) <= 512) { constexpr int VPL = 2; CALL; }                                      \
