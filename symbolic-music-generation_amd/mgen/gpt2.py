@@ -202,6 +202,12 @@ class MidiGPT2LM(MidiLM):
         dy = torch.empty(T, d, dtype=bf, device=dev) if p_r > 0 else None   # gradient of a dropped projection output
         dh = torch.empty(T, d, dtype=f32, device=dev)
         dh_lp = torch.empty(T, d, dtype=bf, device=dev)
+        # The four weight gradients of a layer as ONE launch at the end of the layer (a quarter of the reduction slices
+        # and atomics of four launches): the output gradients the MLP branch saw must then outlive the ones the
+        # attention branch sees, hence second buffers.
+        group = not full
+        dh_lp2 = torch.empty(T, d, dtype=bf, device=dev) if group else dh_lp
+        dy2 = torch.empty(T, d, dtype=bf, device=dev) if (group and p_r > 0) else dy
         ops.layernorm_bwd(dxN, h_last, self.transformer.ln_f.weight, meanN, rstdN, dh, dh_lp,
                           self._view(self.flat_grad, "transformer.ln_f.weight"),
                           self._view(self.flat_grad, "transformer.ln_f.bias"), accumulate=False)
@@ -222,25 +228,32 @@ class MidiGPT2LM(MidiLM):
                 ops.dropout(dh_lp, dy, p_r, keys[3 * l + 3])
                 g = dy
             ops.conv1d_dgrad(g, v.s_mproj, dact)
-            ops.conv1d_wgrad(g, act, v.g_mproj, v.g_mproj_b)
+            wgrad = ops.conv1d_bias_grad if group else ops.conv1d_wgrad   # (grouped: only the bias column sums now)
+            wgrad(g, act, v.g_mproj, v.g_mproj_b)
             ops.gelu_new_bwd(fc, dact, dfc)
             ops.conv1d_dgrad(dfc, v.s_fc, dx)
-            ops.conv1d_wgrad(dfc, x2, v.g_fc, v.g_fc_b)
+            wgrad(dfc, x2, v.g_fc, v.g_fc_b)
+            g_mlp, dh_mlp = g, dh_lp
+            dh_lp = dh_lp2            # (the same buffer unless the weight gradients are grouped)
             ops.layernorm_bwd(dx, h_mid, v.w_ln2w, mean2, rstd2, dh, dh_lp, v.g_ln2w, v.g_ln2b, accumulate=True)
             # ---- attention branch
             g = dh_lp
             if p_r > 0:
-                ops.dropout(dh_lp, dy, p_r, keys[3 * l + 2])
-                g = dy
+                ops.dropout(dh_lp, dy2, p_r, keys[3 * l + 2])
+                g = dy2
             ops.conv1d_dgrad(g, v.s_proj, datt)
-            ops.conv1d_wgrad(g, att, v.g_proj, v.g_proj_b)
+            wgrad(g, att, v.g_proj, v.g_proj_b)
             qp, kp, vp = qkv.data_ptr(), qkv.data_ptr() + esz * d, qkv.data_ptr() + 2 * esz * d
             dqp, dkp, dvp = dqkv.data_ptr(), dqkv.data_ptr() + esz * d, dqkv.data_ptr() + 2 * esz * d
             ops.attn_bwd(qp, kp, vp, att.data_ptr(), datt.data_ptr(), lse, delta, dqp, dkp, dvp,
                          3 * d, 3 * d, 3 * d, d, d, 3 * d, 3 * d, 3 * d, B, S, H, H, Dh, scale, f32=full,
                          drop_p=p_a, drop_key=keys[3 * l + 1] if keys else 0)
             ops.conv1d_dgrad(dqkv, v.s_attn, dx)
-            ops.conv1d_wgrad(dqkv, x1, v.g_attn, v.g_attn_b)
+            wgrad(dqkv, x1, v.g_attn, v.g_attn_b)
+            if group:   # Conv1D weights are [in][out]: dW += x^T dy
+                ops.linear_wgrad_group([(act, g_mlp, v.g_mproj), (x2, dfc, v.g_fc), (att, g, v.g_proj),
+                                        (x1, dqkv, v.g_attn)])
+            dh_lp = dh_mlp            # the layer below reads (and keeps) this one
             ops.layernorm_bwd(dx, h_in, v.w_ln1w, mean1, rstd1, dh, dh_lp if l > 0 else None, v.g_ln1w, v.g_ln1b,
                               accumulate=True)
             saved[l] = None

@@ -229,6 +229,13 @@ def conv1d_wgrad(dy, x, dw, db):
          _stream())
 
 
+def conv1d_bias_grad(dy, x, dw, db):
+    """db[N] += column sums of dy (the signature of conv1d_wgrad: its weight gradient is taken elsewhere)."""
+    T, N = dy.shape
+    call("mgen_colsum_f32" if dy.dtype == torch.float32 else "mgen_colsum_bf16", _p(dy), dy.stride(0), _p(db), T, N,
+         _stream())
+
+
 def layernorm_fwd(x, w, b, y, mean, rstd, eps):
     T, d = x.shape
     call("mgen_layernorm_fwd", _p(x), _p(w), _p(b), _p(y), _p(mean), _p(rstd), T, d, eps,
