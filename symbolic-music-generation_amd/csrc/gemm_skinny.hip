@@ -153,6 +153,8 @@ int sk_launch(const void* A, const void* W, void* C, int M, int N, int K, long l
 extern "C" int mgen_gemm_skinny_fits(int M, int N, int K, long lda, long ldw, long ldc, int slabs) {
     if (M < 1 || M > 1024 || N < 64 || N % 64 || N > 16384 || K < 512 || K % 512) return 0;
     if (lda % 8 || ldw % 8 || ldc % 4) return 0;
+    // (buffer offsets of the LDS-DMA pieces are 32-bit: a tile's last row must start below 2 GiB)
+    if (63L * ldw * 2 >= (1L << 31) || (long)(M - 1) * lda * 2 >= (1L << 31)) return 0;
     if (!slabs && K != 512) return 0;
     return 1;
 }
