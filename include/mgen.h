@@ -312,7 +312,7 @@ int mgen_ce_finalize(const float* row_loss, long T, const float* inv_count, floa
 
 /* lm_head + shifted cross entropy, forward and backward, with the chunk loop inside the library: per chunk of at most
  * chunk_tokens rows, logits = x W^T -> cross entropy in place -> dx = dlogits W -> dW (+)= dlogits^T x (a plain store
- * for the first 8192 rows of the call, accumulating launches after them). Replaces `logits = self.lm_head(hidden)` +
+ * for the first chunk of the call, accumulating launches after it). Replaces `logits = self.lm_head(hidden)` +
  * `self.loss_function(...)` of Qwen3ForCausalLM.forward (TF models/qwen3/modeling_qwen3.py:495-499 ->
  * TF loss/loss_utils.py:49-71) and autograd through both, as called from /root/reference/src/model/model.py:142-143.
  * x [B*S][ldx] bf16, W [V][ldw] bf16, labels int64 [B][S]; loss fp32 scalar (device); with_grad: dx [B*S][lddx] bf16 and

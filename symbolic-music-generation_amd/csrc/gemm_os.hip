@@ -42,6 +42,8 @@ struct OsArgs {
     int M, N, K;
     int nbm, nbn;
     int splitk, kper;   // reduction slices of kper indices (a multiple of OS_BK)
+    int kseg;           // a workgroup walks its slice in segments of kseg indices (a multiple of OS_BK), each with a
+                        // buffer descriptor of its own: 32-bit buffer offsets reach 4 GiB, a slice may be longer
 };
 
 // AKM / BKM: the operand is stored [reduction][output index] (else [output index][reduction])
@@ -51,11 +53,24 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
     constexpr bool ROWMAJOR_OUT = OUT != OS_OUT_F32 && OUT != OS_OUT_F32_ACC;
     const int tm = t / g.nbn, tn = t % g.nbn;
     const int m0 = tm * 256, n0 = tn * 256;
-    const int kbeg = kslice * g.kper;
-    const int kend = min(g.K, kbeg + g.kper);
-    const int nslot = (kend - kbeg) / OS_BK;
-    if (nslot <= 0) return;
+    const int kbeg0 = kslice * g.kper;
+    const int kend0 = min(g.K, kbeg0 + g.kper);
+    if (kend0 - kbeg0 < OS_BK) return;
     const unsigned lds0 = lds_addr(smem);
+
+    // ---- compute role: rows 128 wm.. of the tile from A image wm, columns 128 wn.. from B image wn
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int kbeg = kbeg0; kbeg < kend0; kbeg += g.kseg) {   // one segment of the slice per pass (usually one pass)
+    const int kend = min(kend0, kbeg + g.kseg);
+    const int nslot = (kend - kbeg) / OS_BK;
 
     // ---- loader role: this wave fills one of the four images of every step with 8 one-KiB pieces. The buffer
     // descriptor starts at the image's first element of this workgroup's slice, so offsets stay far below 4 GiB.
@@ -94,16 +109,6 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (sl & 3) * OS_SLOT + wave * OS_IMG + pc * 1024);
         dma_piece(rs, voff[pc & 3], dst, soff);
     };
-
-    // ---- compute role: rows 128 wm.. of the tile from A image wm, columns 128 wn.. from B image wn
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl)
@@ -157,9 +162,10 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
         frags(nxt, 0, fa0, fb0);
         step(fa1, fb1, s + 3, 4);
     }
-    // no LDS-DMA may be pending when the wave ends; the row-major outputs reuse the ring as a staging area once every
-    // wave has left the loop
+    // no LDS-DMA may be pending when the wave ends (or refills the ring for the next segment); the row-major outputs
+    // reuse the ring as a staging area once every wave has left the loop
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }   // segments
 
     // the output addresses are derived from a lane index the compiler cannot trace back past the loop: it would
     // otherwise compute them in front of the loop and carry (or spill) them through it
@@ -533,11 +539,10 @@ bool mgen_gemm_os_fits(int M, int N, int K, long lda, long ldb, long ldc, long l
     if (!(wgrad || (dgrad && !(e && e[0] == '4')) || (proj && e && e[0] == '2'))) return false;
     if (wgrad) {
         if (K < 2048 || (M % 8) || (N % 8)) return false;
-        // buffer offsets are 32-bit: one workgroup's reduction slice of either operand must stay below 4 GiB. A product
-        // that is added to its output can be cut into slices for that (slices of at least 1024 rows), a plain store not
+        // buffer offsets are 32-bit: a workgroup walks its reduction range in segments below 4 GiB of either operand,
+        // each with a descriptor of its own; a segment must hold at least 1024 rows
         const long ldmax = lda > ldb ? lda : ldb;
-        const long rows = out_mode == OS_OUT_F32_ACC ? (K < 1024 ? K : 1024) : K;
-        if (rows * ldmax * 2 >= (1L << 32)) return false;
+        if (1024L * ldmax * 2 >= (1L << 32)) return false;
         return true;
     }
     // the products with few output columns: whole 256-row tiles (rows beyond the operand would be read), at least as
@@ -568,16 +573,15 @@ int mgen_gemm_os_launch(const void* A, const void* B, void* C, const void* resid
         static const bool many = [] { const char* v = getenv("MGEN_GEMM_OS_SK_MANY"); return v && v[0] == '1'; }();
         sk = os_pick_slices(tiles, steps, many);
     }
-    if (out_mode == OS_OUT_F32_ACC) {
-        // and at least as many slices as keep a slice of either operand below 4 GiB (32-bit buffer offsets)
-        const long ldmax = lda > ldb ? lda : ldb;
-        const long max_rows = ((1L << 32) - 1) / (ldmax * 2) / OS_BK * OS_BK;
-        const int need = (int)((K + max_rows - 1) / max_rows);
-        if (sk < need) sk = need;
-    }
     const int per = (steps + sk - 1) / sk;
     g.kper = per * OS_BK;
     g.splitk = (steps + per - 1) / per;
+    g.kseg = g.kper;
+    if (transA && transB) {   // both operands stored [reduction][...]: segments below 4 GiB (32-bit buffer offsets)
+        const long ldmax = lda > ldb ? lda : ldb;
+        const long max_rows = ((1L << 32) - 1) / (ldmax * 2) / OS_BK * OS_BK;
+        if (g.kseg > max_rows) g.kseg = (int)max_rows;
+    }
     if (transA && transB)
         return out_mode == OS_OUT_F32_ACC ? os_launch<true, true, OS_OUT_F32_ACC>(g, stream)
                                           : os_launch<true, true, OS_OUT_F32>(g, stream);
@@ -631,17 +635,16 @@ extern "C" int mgen_gemm_bf16_wgrad_group(int n, const void* const* A, const voi
     const int steps = K / OS_BK;
     static const bool many = [] { const char* v = getenv("MGEN_GEMM_OS_SK_MANY"); return !(v && v[0] == '0'); }();
     int sk = os_pick_slices(tiles, steps, many);
-    {   // at least as many slices as keep a slice of the widest operand below 4 GiB (32-bit buffer offsets)
-        long ldmax = 8;
-        for (int i = 0; i < n; ++i) ldmax = lda[i] > ldmax ? lda[i] : (ldb[i] > ldmax ? ldb[i] : ldmax);
-        for (int i = 0; i < n; ++i) ldmax = ldb[i] > ldmax ? ldb[i] : ldmax;
-        const long max_rows = ((1L << 32) - 1) / (ldmax * 2) / OS_BK * OS_BK;
-        const int need = (int)((K + max_rows - 1) / max_rows);
-        if (sk < need) sk = need;
-    }
     const int per = (steps + sk - 1) / sk;
     const int splitk = (steps + per - 1) / per;
-    for (int i = 0; i < n; ++i) { gg.p[i].kper = per * OS_BK; gg.p[i].splitk = splitk; }
+    for (int i = 0; i < n; ++i) {
+        gg.p[i].kper = per * OS_BK;
+        gg.p[i].splitk = splitk;
+        // segments of a slice below 4 GiB of either operand (32-bit buffer offsets)
+        const long ldmax = lda[i] > ldb[i] ? lda[i] : ldb[i];
+        const long max_rows = ((1L << 32) - 1) / (ldmax * 2) / OS_BK * OS_BK;
+        gg.p[i].kseg = per * OS_BK > max_rows ? (int)max_rows : per * OS_BK;
+    }
     static bool asked[16] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;

@@ -5,8 +5,8 @@
 // are not ignore_index) and autograd through both, as reached from /root/reference/src/model/model.py:142-143.
 //
 // Per chunk of at most chunk_tokens rows: logits = x W^T (bf16) -> cross entropy rewrites them in place as
-// d(loss)/d(logits) -> dx = dlogits W -> dW += dlogits^T x. The first 8192 rows of the call store dW (no zero fill by
-// the caller), everything after them is added: one launch per chunk, as few atomics as possible.
+// d(loss)/d(logits) -> dx = dlogits W -> dW += dlogits^T x. The first chunk of the call stores dW (no zero fill by
+// the caller), every later chunk is added: one launch per chunk, as few atomics as possible.
 // The caller owns every buffer; mgen_lmhead_ce_workspace_bytes says how large the workspace must be.
 #include "common.h"
 
@@ -70,16 +70,11 @@ extern "C" int mgen_lmhead_ce_fwd_bwd(const void* x, long ldx, const void* W, lo
         if (int e = mgen_gemm_bf16(logits, W, dxb + t0 * lddx, nullptr, (int)n, d, V, ld, ldw, lddx, 0, 0, 1, 0, 1.0f, stream))
             return e;
         if (!dW) continue;
-        // dW (+)= dlogits[c]^T x[c]: a plain store for the first 8192 rows of the call, accumulating launches after them
-        long r0 = 0;
-        while (r0 < n) {
-            const long rn = first ? (n - r0 < 8192 ? n - r0 : 8192) : n - r0;
-            if (int e = mgen_gemm_bf16(logits + r0 * ld, xc + r0 * ldx, dW, nullptr, V, d, (int)rn, ld, ldx, d, 0, 1, 1,
-                                       first ? /*fp32 store*/ 1 : /*fp32 accumulate*/ 2, 1.0f, stream))
-                return e;
-            first = false;
-            r0 += rn;
-        }
+        // dW (+)= dlogits[c]^T x[c]: a plain store for the first chunk of the call, accumulating launches after it
+        if (int e = mgen_gemm_bf16(logits, xc, dW, nullptr, V, d, (int)n, ld, ldx, d, 0, 1, 1,
+                                   first ? /*fp32 store*/ 1 : /*fp32 accumulate*/ 2, 1.0f, stream))
+            return e;
+        first = false;
     }
     return mgen_ce_finalize(row_loss, T, inv_count, loss, stream);
 }

@@ -739,9 +739,8 @@ class MidiLM(GenerationMixin, nn.Module):
                 # dxN[c] = dlogits[c] @ W ; dW += dlogits[c]^T @ xN[c]
                 dl = ops.presplit(logits)
                 ops.gemm_any(dl, W, dxN[t0:t0 + n], n, d, V, ld, W.stride(0), d, False, True, ops.OUT_BF16)
-                # the weight-gradient product: the very first launch stores (8192 tokens), everything after it is
-                # added, as much of the chunk per launch as possible (the kernel cuts the token range into slices
-                # of less than 4 GiB of dlogits rows; one launch wastes less in its last round of workgroups)
+                # the weight-gradient product: one launch per chunk; the first stores, every later one is added (the
+                # kernel walks the token range in segments of less than 4 GiB of dlogits rows)
                 if self.lora is not None:
                     pass   # frozen base: no weight gradient for the head
                 elif isinstance(dl, ops.W2):
@@ -751,7 +750,7 @@ class MidiLM(GenerationMixin, nn.Module):
                 else:
                     r0 = 0
                     while r0 < n:
-                        rn = min(8192, n - r0) if (first or _LM_WGRAD_8K) else n - r0
+                        rn = min(8192, n - r0) if _LM_WGRAD_8K else n - r0
                         ops.gemm(dl[r0:r0 + rn], xc[r0:r0 + rn], grad_buf, V, d, rn, ld, xc.stride(0), d,
                                  True, True, ops.OUT_F32 if first else ops.OUT_F32_ACC)
                         first = False
