@@ -216,6 +216,8 @@ def main():
         wl = f"GPT-2 variant (L6 d512 H8xDh64 I2048 V30000 tied, dropout {args.pdrop})"
     else:
         cfg = default_decoder()
+        if os.environ.get("MGEN_LM_CHUNK"):   # lm_head chunk size in tokens (measurements)
+            cfg.lm_head_chunk_tokens = int(os.environ["MGEN_LM_CHUNK"])
         wl = "default decoder (MidiQwen shape: L14 d512 H8xDh128 I2048 V151936 tied)"
     model = (MidiGPT2LM if args.model == "gpt2" else MidiLM)(cfg, device=dev, seed=0)
     trainer = Trainer(model, lr=5e-5, num_epochs=12, steps_per_epoch=1000, warmup=1000, max_grad_norm=1.0)
