@@ -167,9 +167,9 @@ __device__ __forceinline__ void os_body(const OsArgs& g, char* smem, int lane, i
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }   // segments
 
-    // the output addresses are derived from a lane index the compiler cannot trace back past the loop: it would
-    // otherwise compute them in front of the loop and carry (or spill) them through it
-    asm volatile("" : "+v"(lane));
+    // the output addresses are derived from a lane index taken here, after the loop: from the function's argument the
+    // compiler would compute them in front of the loop and carry (or spill) them, or the index itself, through it
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     const int h = lane >> 5, r = lane & 31;
     if constexpr (!ROWMAJOR_OUT) {
         float* C = reinterpret_cast<float*>(g.C);

@@ -174,6 +174,38 @@ def test_weight_gradient_kernel(ops, M, N, K, acc):
     assert float((new[:, :N] - old[:, :N]).abs().max()) / scale < 2e-6
 
 
+@pytest.mark.parametrize("K,acc", [(4096, False), (8192, True)])
+def test_weight_gradient_kernel_walks_long_reductions_in_segments(ops, K, acc):
+    """An operand whose reduction range spans more than 4 GiB (here: a row pitch of 2 MiB, as the lm_head's
+    dlogits chunk of 32 768 x 151 936 has 10 GB) is walked in segments with a buffer descriptor each. The plain store
+    must equal, bit for bit, the same product taken from a compact copy of the operand (one segment, same summation
+    order); the accumulating form (reduction slices of 2048 = two segments each) up to the order of its atomics."""
+    M, N, lda = 512, 768, 1 << 20
+    g = torch.Generator().manual_seed(K)
+    wide = torch.zeros(K, lda, dtype=torch.bfloat16, device=dev())
+    assert wide.numel() * 2 > (1 << 32)
+    wide[:, :M] = (torch.randn(K, M, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    wide[:, M:M + 256] = 7.0   # columns past M are fetched with the ragged tile and must not reach the output
+    compact = wide[:, :M].contiguous()
+    b = (torch.randn(K, N, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    mode = ops.OUT_F32_ACC if acc else ops.OUT_F32
+    c_wide = torch.full((M, N), 3.0, dtype=torch.float32, device=dev())
+    c_comp = torch.full((M, N), 3.0, dtype=torch.float32, device=dev())
+    ops.gemm(wide, b, c_wide, M, N, K, lda, N, N, True, True, mode)
+    ops.gemm(compact, b, c_comp, M, N, K, M, N, N, True, True, mode)
+    ref = compact.float().t() @ b.float() + (3.0 if acc else 0.0)
+    scale = float(ref.abs().max())
+    assert float((c_wide - ref).abs().max()) / scale < 2e-5
+    if acc:
+        assert float((c_wide - c_comp).abs().max()) / scale < 2e-6
+    else:
+        assert torch.equal(c_wide, c_comp)
+    # the same with the wide operand on the other side
+    c2 = torch.full((N, M), 3.0, dtype=torch.float32, device=dev())
+    ops.gemm(b, wide, c2, N, M, K, N, lda, M, True, True, mode)
+    assert float((c2 - ref.t()).abs().max()) / scale < 2e-5
+
+
 @pytest.mark.parametrize("kind", ["dgrad", "proj"])
 def test_output_stationary_row_major_outputs(ops, kind):
     """Input-gradient form (A reduction-contiguous, B stored [K][N], bf16 output) and residual-projection form (both
