@@ -23,6 +23,9 @@ typedef void* mgen_stream_t; /* hipStream_t */
 /* ---- runtime ------------------------------------------------------------------------------------------------ */
 const char* mgen_last_error(void);
 int mgen_version(void);
+/* identity of the kernel sources the library was built from (16 hex digits: a SHA-256 prefix over csrc/); the Python
+ * loader refuses an in-tree library whose identity differs from the sources beside it. */
+const char* mgen_source_id(void);
 /* name of the device's gfx architecture into name[name_len]; returns the CU count. */
 int mgen_device_info(int device, char* name, int name_len);
 

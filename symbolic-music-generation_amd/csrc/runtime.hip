@@ -25,6 +25,12 @@ extern "C" const char* mgen_last_error(void) { return g_err; }
 
 extern "C" int mgen_version(void) { return 100; }
 
+// identity of the sources this library was built from (mgen/_srcid.py, passed in by the Makefile)
+#ifndef MGEN_SOURCE_ID
+#define MGEN_SOURCE_ID "unknown"
+#endif
+extern "C" const char* mgen_source_id(void) { return MGEN_SOURCE_ID; }
+
 // Fills name[] with the gcnArchName of `device` and returns the CU count (negative on error).
 extern "C" int mgen_device_info(int device, char* name, int name_len) {
     hipDeviceProp_t p;

@@ -105,6 +105,21 @@ class MgenError(RuntimeError):
     pass
 
 
+def _check_source_id(l):
+    """The in-tree library must have been built from the sources beside it: a library left behind by a failed or
+    interrupted build would otherwise run in place of the kernels one is looking at. Skipped for a library named by
+    MGEN_LIB (another build on purpose) and when the sources are not there (an installed package)."""
+    csrc = os.path.join(_HERE, "..", "csrc")
+    if os.environ.get("MGEN_LIB") or not os.path.isdir(csrc):
+        return
+    from ._srcid import source_id
+    built, here = l.mgen_source_id().decode(), source_id(csrc)
+    if built != here:
+        raise MgenError(
+            f"{LIB_PATH} was built from other sources (library {built}, {os.path.normpath(csrc)} {here}): "
+            "run `make -C symbolic-music-generation_amd/csrc`")
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -120,6 +135,9 @@ def lib():
         l.mgen_last_error.restype = ctypes.c_char_p
         l.mgen_last_error.argtypes = []
         l.mgen_version.restype = ctypes.c_int
+        l.mgen_source_id.restype = ctypes.c_char_p
+        l.mgen_source_id.argtypes = []
+        _check_source_id(l)
         l.mgen_sumsq_partial_count.restype = ctypes.c_int
         l.mgen_gemm_slab_count.argtypes = [I, I]
         l.mgen_gemm_slab_count.restype = ctypes.c_int

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     from mgen import _lib
     declared = set(header_functions())
-    bound = set(_lib.SIGNATURES) | {"mgen_last_error", "mgen_version", "mgen_sumsq_partial_count", "mgen_device_info",
+    bound = set(_lib.SIGNATURES) | {"mgen_last_error", "mgen_version", "mgen_source_id", "mgen_sumsq_partial_count", "mgen_device_info",
                                      "mgen_attn_decode_workspace", "mgen_gemm_slab_count", "mgen_gemm_skinny_fits", "mgen_lmhead_ce_workspace_bytes", "mgen_decode_layer_fits"}
     assert declared == bound, (declared - bound, bound - declared)
 
@@ -55,3 +55,21 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1 and b"d" in l.mgen_last_error()
     with pytest.raises(_lib.MgenError):
         _lib.call("mgen_adamw_step", 16, 16, 16, 16, None, 10, None, 1e-3, 0.9, 0.95, 1e-5, 0.1, 1, None)
+
+
+def test_library_was_built_from_the_sources_beside_it():
+    """A library left over from older sources (a failed build) must not pass for the current one: the loader compares
+    the source identity compiled into the library with the one of csrc/ and refuses a mismatch."""
+    from mgen import _lib
+    from mgen._srcid import source_id
+    l = _lib.lib()
+    csrc = os.path.join(ROOT, "symbolic-music-generation_amd", "csrc")
+    assert l.mgen_source_id().decode() == source_id(csrc)
+
+    class Stale:
+        @staticmethod
+        def mgen_source_id():
+            return b"0123456789abcdef"
+    if not os.environ.get("MGEN_LIB"):
+        with pytest.raises(_lib.MgenError, match="other sources"):
+            _lib._check_source_id(Stale)
