@@ -113,6 +113,10 @@ def _check_source_id(l):
     if os.environ.get("MGEN_LIB") or not os.path.isdir(csrc):
         return
     from ._srcid import source_id
+    if not hasattr(l, "mgen_source_id"):
+        raise MgenError(f"{LIB_PATH} predates its sources (no mgen_source_id): run `make -C symbolic-music-generation_amd/csrc`")
+    l.mgen_source_id.restype = ctypes.c_char_p
+    l.mgen_source_id.argtypes = []
     built, here = l.mgen_source_id().decode(), source_id(csrc)
     if built != here:
         raise MgenError(
@@ -135,8 +139,6 @@ def lib():
         l.mgen_last_error.restype = ctypes.c_char_p
         l.mgen_last_error.argtypes = []
         l.mgen_version.restype = ctypes.c_int
-        l.mgen_source_id.restype = ctypes.c_char_p
-        l.mgen_source_id.argtypes = []
         _check_source_id(l)
         l.mgen_sumsq_partial_count.restype = ctypes.c_int
         l.mgen_gemm_slab_count.argtypes = [I, I]
