@@ -68,6 +68,12 @@ int mgen_slab_resid_rmsnorm(const float* slabs, int nslabs, long slab_stride, co
  * the backward. d % 4 == 0, d <= 2048. */
 int mgen_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, long T, int d, float eps, int out_bf16,
                      mgen_stream_t stream);
+/* The residual addition that ends a decoder layer's attention or MLP branch (TF models/qwen3/modeling_qwen3.py:316,322)
+ * and the RMSNorm that follows it, in one pass: h_out[T,d] (fp32) = resid + float(y), y = the branch's last projection
+ * in bf16 [T][ldy]; x_out (bf16 [T,d]) = w * (h_out * rstd); rstd[T] saved for the backward (may be null). Same bits as
+ * mgen_gemm_bf16 with out_mode 3 followed by mgen_rmsnorm_fwd; lets that projection run as a bf16-output product. */
+int mgen_resid_rmsnorm_fwd(const float* resid, const void* y, long ldy, const float* w, float* h_out, void* x_out,
+                           float* rstd, long T, int d, float eps, mgen_stream_t stream);
 /* autograd backward of the above: dres (fp32 [T,d]) = (accumulate ? dres : 0) + dx; optional copy of the updated dres
  * in the dy dtype (dres_lp, may be null); dw[d] += sum_rows dy * x * rstd. The blocks of a launch meet in a small
  * device array that the library owns (one per GPU): calls on one stream are ordered, calls that overlap on one GPU

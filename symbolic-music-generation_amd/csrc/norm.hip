@@ -78,6 +78,65 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
     }
 }
 
+// h = resid + float(y) (y: the bf16 output of a residual branch's last projection), then the RMSNorm of h as above: the
+// residual addition of the decoder layer (transformers models/qwen3/modeling_qwen3.py:316,322) and the norm that
+// follows it (:59-64) in one pass over the row. Same arithmetic, in the same order, as the fp32 residual epilogue of
+// the projection followed by rmsnorm_fwd_kernel: same bits.
+template <int VPL>
+__global__ __launch_bounds__(256) void resid_rmsnorm_fwd_kernel(const float* __restrict__ resid,
+                                                                const bf16* __restrict__ y, long ldy,
+                                                                const float* __restrict__ w, float* __restrict__ h_out,
+                                                                bf16* __restrict__ x_out, float* __restrict__ rstd_out,
+                                                                long T, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    f32x4 wv[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        wv[i] = c < d ? Vec4<float>::load(w + c) : f32x4{0, 0, 0, 0};
+    }
+    for (long row0 = wave0; row0 < T; row0 += 2 * nwaves) {
+        const long row1 = row0 + nwaves;
+        f32x4 xa[VPL], xb[VPL];
+        bf16x4 ya[VPL], yb[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const bool in0 = c < d, in1 = c < d && row1 < T;
+            xa[i] = in0 ? ld_stream(reinterpret_cast<const f32x4*>(resid + row0 * d + c)) : f32x4{0, 0, 0, 0};
+            ya[i] = in0 ? ld_stream(reinterpret_cast<const bf16x4*>(y + row0 * ldy + c)) : bf16x4{};
+            xb[i] = in1 ? ld_stream(reinterpret_cast<const f32x4*>(resid + row1 * d + c)) : f32x4{0, 0, 0, 0};
+            yb[i] = in1 ? ld_stream(reinterpret_cast<const bf16x4*>(y + row1 * ldy + c)) : bf16x4{};
+        }
+        auto finish = [&](long row, f32x4 (&xv)[VPL], const bf16x4 (&yv)[VPL]) {
+            float ss = 0.f;
+            float* hr = h_out + row * d;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                xv[i] += f32x4{(float)yv[i][0], (float)yv[i][1], (float)yv[i][2], (float)yv[i][3]};
+                if (c < d) *reinterpret_cast<f32x4*>(hr + c) = xv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                ss += xv[i][0] * xv[i][0] + xv[i][1] * xv[i][1] + xv[i][2] * xv[i][2] + xv[i][3] * xv[i][3];
+            ss = wave_sum(ss);
+            const float r = rsqrtf(ss / (float)d + eps);
+            if (lane == 0 && rstd_out) rstd_out[row] = r;
+            bf16* xr = x_out + row * d;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < d) Vec4<bf16>::store(xr + c, wv[i] * (xv[i] * r));
+            }
+        };
+        finish(row0, xa, ya);
+        if (row1 < T) finish(row1, xb, yb);
+    }
+}
+
 // Gain gradient of mgen_rmsnorm_bwd. Every workgroup of a launch leaves its partial gain-gradient row in a row of its
 // own in a device array (plain stores), and a second small launch on the same stream adds the rows, column by column,
 // into dw: no atomics, so the result does not depend on the order the workgroups finish in. (fp32 atomics on device
@@ -284,6 +343,22 @@ extern "C" int mgen_rmsnorm_fwd(const float* x, const float* w, void* y, float* 
             hipLaunchKernelGGL((rmsnorm_fwd_kernel<VPL, float>), grid, block, 0, stream, x, w, (float*)y, rstd, T, d, eps);
     });
     return mgen_check_launch("mgen_rmsnorm_fwd");
+}
+
+extern "C" int mgen_resid_rmsnorm_fwd(const float* resid, const void* y, long ldy, const float* w, float* h_out,
+                                      void* x_out, float* rstd, long T, int d, float eps, hipStream_t stream) {
+    MGEN_REQUIRE(resid && y && w && h_out && x_out, "mgen_resid_rmsnorm_fwd: null pointer");
+    MGEN_REQUIRE(T > 0 && d > 0 && d % 4 == 0 && d <= 2048 && ldy >= d && ldy % 4 == 0,
+                 "mgen_resid_rmsnorm_fwd: need 0<d<=2048, d%%4==0, ldy>=d, ldy%%4==0 (d=%d, ldy=%ld)", d, ldy);
+    MGEN_REQUIRE(((uintptr_t)resid % 16) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)h_out % 16) == 0 &&
+                     ((uintptr_t)x_out % 8) == 0 && ((uintptr_t)w % 16) == 0,
+                 "mgen_resid_rmsnorm_fwd: operands must be 16-byte (fp32) / 8-byte (bf16) aligned");
+    const dim3 grid(norm_grid(T)), block(256);
+    DISPATCH_VPL(d, {
+        hipLaunchKernelGGL((resid_rmsnorm_fwd_kernel<VPL>), grid, block, 0, stream, resid, (const bf16*)y, ldy, w, h_out,
+                           (bf16*)x_out, rstd, T, d, eps);
+    });
+    return mgen_check_launch("mgen_resid_rmsnorm_fwd");
 }
 
 extern "C" int mgen_rmsnorm_bwd(const void* dy, const float* x, const float* w, const float* rstd, float* dres,

@@ -18,6 +18,7 @@ SIGNATURES = {
     "mgen_gemm_bf16_slabs": [P, P, P, I, I, I, L, L, I, I, I, P],
     "mgen_slab_resid_rmsnorm": [P, I, L, P, P, P, P, L, I, F, I, P],
     "mgen_rmsnorm_fwd": [P, P, P, P, L, I, F, I, P],
+    "mgen_resid_rmsnorm_fwd": [P, P, L, P, P, P, P, L, I, F, P],
     "mgen_rmsnorm_bwd": [P, P, P, P, P, P, P, L, I, I, I, P],
     "mgen_rope_table": [P, P, I, I, P],
     "mgen_qknorm_rope_fwd": [P, L, P, P, L, L, P, P, P, P, I, L, I, I, I, F, I, P],

@@ -33,6 +33,8 @@ POS4D_HEAD_OUT = 16  # 4-D position model: 8 (cos, sin) pairs (/root/reference/s
 
 # MGEN_LM_WGRAD_8K=1: the lm_head weight gradient in launches of 8192 tokens (same-box comparisons)
 _LM_WGRAD_8K = os.environ.get("MGEN_LM_WGRAD_8K", "0") == "1"
+# MGEN_SPLIT_PROJ=0: o_proj / down_proj with the fp32 residual epilogue + a separate norm (same-box comparisons)
+_SPLIT_PROJ = os.environ.get("MGEN_SPLIT_PROJ", "1") != "0"
 # MGEN_ROW_PAD=0: no padding of the gradient activations' rows (same-box comparisons)
 _ROW_PAD = int(os.environ.get("MGEN_ROW_PAD", "64"))
 _ATT_PAD = int(os.environ.get("MGEN_ATT_PAD", str(_ROW_PAD)))
@@ -400,7 +402,9 @@ class MidiLM(GenerationMixin, nn.Module):
         """Transposed bf16 copies [in_features][hidden] of every layer's o_proj and down_proj weights, or None.
         With hidden_size 512 the input gradients of those two projections (dx = dy @ W, reduction over the 512
         outputs) run on the GEMM kernel that keeps a 256-token panel of dy in registers, which wants both operands
-        with the reduction index contiguous. Two batched transpose launches per optimizer step."""
+        with the reduction index contiguous. The forward products of the two projections read the same copies as
+        [reduction][output column] operands of the output-stationary kernel. Two batched transpose launches per
+        optimizer step."""
         cfg = self.cfg
         if cfg.hidden_size != 512 or self.flat_shadow_lo is not None or cfg.arch != "llama":
             return None
@@ -634,11 +638,25 @@ class MidiLM(GenerationMixin, nn.Module):
             ops.embedding_fwd(inp, self.model.embed_tokens.weight, h, self._err_flag)
         lo = self.lora
         lkeys = lo.drop_keys(self.training and cache is None and pos is None) if lo is not None else None
+        # Split residual projections: o_proj and down_proj as bf16-output products through the transposed weight copies
+        # (reduction-contiguous tokens against [reduction][512] weights: the fastest form of these shapes), and the
+        # residual addition in the same pass as the RMSNorm that follows. Same bits as the fp32 residual epilogue
+        # followed by the norm; taken when the products fill the output-stationary kernel's whole tiles. (Hidden size
+        # 512 only, where the copies exist for the backward anyway: with copies made for it the 650M model's step
+        # measured 176.7-177.6 against 177.6-177.9 ms at 8 x 4096 tokens and the same at 1 x 16 384.)
+        wt = None
+        if (_SPLIT_PROJ and lo is None and not f32 and not cfg.pos4d and not self._ln and T % 256 == 0
+                and (T // 256) * (d // 256) >= 256):
+            wt = self._dgrad_weights_t()
+        nxt = None   # (x1, rstd1) of the coming layer when the previous layer's last kernel has formed them
         for l, v in enumerate(self._layers):
             la = lo.layers[l] if lo is not None else None
             lk = lkeys[l] if lkeys is not None else (None,) * 5   # adapter dropout keys: qkv, o, gate, up, down
-            x1 = torch.empty(T, d, dtype=bf, device=dev)
-            rstd1 = self._norm_fwd(h, v.w_ln1, v.w_ln1b, x1)
+            if nxt is None:
+                x1 = torch.empty(T, d, dtype=bf, device=dev)
+                rstd1 = self._norm_fwd(h, v.w_ln1, v.w_ln1b, x1)
+            else:
+                x1, rstd1 = nxt
             # (training without adapters: 128 bytes of row padding, so that the 6 KiB pitch of the rows the QKV product
             # stores by column segments is not a multiple of 2 KiB - 210 -> 179 us for that product)
             qpad = _ROW_PAD if (save is not None and lo is None and not f32 and not cfg.pos4d and cache is None
@@ -675,12 +693,20 @@ class MidiLM(GenerationMixin, nn.Module):
                 att_o = torch.empty(T, H * Dh, dtype=bf, device=dev)
                 ops.rotate4d(att, att_o, cs, T, H, Dh, inverse=True)
             h_mid = torch.empty(T, d, dtype=torch.float32, device=dev)
-            if fused:
-                t_o = lo.fwd_fused(att_o, v.s_o, la, "o", h_mid, H * Dh, d, ops.OUT_F32_RESID_BF16ROUND, h, key=lk[1])
-            else:
-                ops.linear_fwd(att_o, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
             x2 = torch.empty(T, d, dtype=bf, device=dev)
-            rstd2 = self._norm_fwd(h_mid, v.w_ln2, v.w_ln2b, x2)
+            if wt is not None:
+                yb = torch.empty(T, d, dtype=bf, device=dev)
+                # att_o @ W_o^T with W_o^T stored [H * Dh][d]: the input-gradient form of the GEMM
+                ops.gemm(att_o, wt[0][l], yb, T, d, H * Dh, att_o.stride(0), d, d, False, True, ops.OUT_BF16)
+                rstd2 = torch.empty(T, dtype=torch.float32, device=dev)
+                ops.resid_rmsnorm_fwd(h, yb, v.w_ln2, h_mid, x2, rstd2, self._norm_eps)
+            else:
+                if fused:
+                    t_o = lo.fwd_fused(att_o, v.s_o, la, "o", h_mid, H * Dh, d, ops.OUT_F32_RESID_BF16ROUND, h,
+                                       key=lk[1])
+                else:
+                    ops.linear_fwd(att_o, v.s_o, h_mid, ops.OUT_F32_RESID_BF16ROUND, h)
+                rstd2 = self._norm_fwd(h_mid, v.w_ln2, v.w_ln2b, x2)
             gu = torch.empty(T, 2 * I, dtype=bf, device=dev)
             act = torch.empty(T, I, dtype=bf, device=dev)   # (row padding measured here too: 0.3-0.8 ms slower)
             if fused:   # t = [t_gate | t_up], then one product with the block-diagonal [B_gate, B_up] behind [Wg; Wu]
@@ -690,7 +716,15 @@ class MidiLM(GenerationMixin, nn.Module):
                 ops.linear_fwd(x2, v.s_gu, gu)
                 ops.swiglu_fwd(gu, act)
             h_out = torch.empty(T, d, dtype=torch.float32, device=dev)
-            if fused:
+            if wt is not None:
+                ops.gemm(act, wt[1][l], yb, T, d, I, act.stride(0), d, d, False, True, ops.OUT_BF16)
+                last = l + 1 == len(self._layers)
+                xn = torch.empty(T, d, dtype=bf, device=dev)
+                rn = torch.empty(T, dtype=torch.float32, device=dev)
+                ops.resid_rmsnorm_fwd(h_mid, yb, self.model.norm.weight if last else self._layers[l + 1].w_ln1, h_out,
+                                      xn, rn, self._norm_eps)
+                nxt = (xn, rn)
+            elif fused:
                 t_down = lo.fwd_fused(act, v.s_down, la, "down", h_out, I, d, ops.OUT_F32_RESID_BF16ROUND, h_mid,
                                       key=lk[4])
             else:
@@ -699,8 +733,11 @@ class MidiLM(GenerationMixin, nn.Module):
                 save.append((h, x1, rstd1, qkv, qk, att, lse, h_mid, x2, rstd2, gu, act, att_o,
                              (t_qkv, t_o, t_gu, t_down, lk) if la is not None else None))
             h = h_out
-        xN = torch.empty(T, d, dtype=bf, device=dev)
-        rstdN = self._norm_fwd(h, self.model.norm.weight, self._final_norm_bias(), xN)
+        if nxt is not None:
+            xN, rstdN = nxt
+        else:
+            xN = torch.empty(T, d, dtype=bf, device=dev)
+            rstdN = self._norm_fwd(h, self.model.norm.weight, self._final_norm_bias(), xN)
         return xN, (h, rstdN, cs)
 
     def _lm_head_loss(self, xN, labels, with_grad: bool, grad_buf=None):

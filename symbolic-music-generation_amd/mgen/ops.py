@@ -272,6 +272,13 @@ def rmsnorm_fwd(x, w, y, rstd, eps):
     call("mgen_rmsnorm_fwd", _p(x), _p(w), _p(y), _p(rstd), T, d, eps, int(y.dtype == torch.bfloat16), _stream())
 
 
+def resid_rmsnorm_fwd(resid, y, w, h_out, x_out, rstd, eps):
+    """h_out = resid + float(y) (y bf16 [T, d], any row pitch); x_out = RMSNorm(h_out) in bf16; rstd [T] or None."""
+    T, d = resid.shape
+    call("mgen_resid_rmsnorm_fwd", _p(resid), _p(y), y.stride(0), _p(w), _p(h_out), _p(x_out), _p(rstd), T, d, eps,
+         _stream())
+
+
 def rmsnorm_bwd(dy, x, w, rstd, dres, dres_lp, dw, accumulate):
     T, d = x.shape
     call("mgen_rmsnorm_bwd", _p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dres_lp), _p(dw), T, d, int(accumulate),

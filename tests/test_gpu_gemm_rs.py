@@ -262,6 +262,66 @@ def test_grouped_weight_gradients(ops):
     assert float((small[0][2] - ref).abs().max()) / float(ref.abs().max()) < 2e-5
 
 
+def test_residual_add_with_norm_equals_residual_epilogue_then_norm(ops):
+    """mgen_resid_rmsnorm_fwd on a bf16 projection output against the projection with the fp32 residual epilogue
+    followed by mgen_rmsnorm_fwd: residual stream, normed rows and rstd bit for bit (also with a padded row pitch)."""
+    T, d, K = 4096, 512, 1024
+    g = torch.Generator().manual_seed(77)
+    a = (torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16).to(dev())
+    w = (torch.randn(d, K, generator=g) * 0.05).to(torch.bfloat16).to(dev())
+    res = torch.randn(T, d, generator=g).to(dev())
+    gain = (1 + 0.1 * torch.randn(d, generator=g)).to(dev())
+    h_ref = torch.empty(T, d, dtype=torch.float32, device=dev())
+    ops.gemm(a, w, h_ref, T, d, K, K, K, d, False, False, ops.OUT_F32_RESID_BF16ROUND, res, d)
+    x_ref = torch.empty(T, d, dtype=torch.bfloat16, device=dev())
+    r_ref = torch.empty(T, dtype=torch.float32, device=dev())
+    ops.rmsnorm_fwd(h_ref, gain, x_ref, r_ref, 1e-6)
+    for pad in (0, 64):
+        y = torch.empty(T, d + pad, dtype=torch.bfloat16, device=dev())[:, :d]
+        ops.gemm(a, w.t().contiguous(), y, T, d, K, K, d, y.stride(0), False, True, ops.OUT_BF16)
+        h = torch.empty_like(h_ref)
+        x = torch.empty_like(x_ref)
+        r = torch.empty_like(r_ref)
+        ops.resid_rmsnorm_fwd(res, y, gain, h, x, r, 1e-6)
+        assert torch.equal(h, h_ref) and torch.equal(x, x_ref) and torch.equal(r, r_ref)
+
+
+def test_split_residual_projections_change_nothing(ops):
+    """Default decoder, 16 x 2048 tokens (the size from which the split path is taken): o_proj / down_proj as bf16
+    products through the transposed weight copies + residual addition inside the following norm, against the fp32
+    residual epilogue + separate norm: loss bit for bit, gradients up to the order of the weight-gradient atomics."""
+    from mgen import MidiLM
+    import mgen.model as mm
+    from mgen.config import default_decoder
+    cfg = default_decoder()
+    cfg.num_hidden_layers = 2
+    cfg.lm_head_chunk_tokens = 16384
+    model = MidiLM(cfg, device="cuda:0", seed=3)
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(3, cfg.vocab_size, (16, 2048), generator=g).to(dev())
+    saved = mm._SPLIT_PROJ
+    outs = []
+    try:
+        for flag in (True, False):
+            mm._SPLIT_PROJ = flag
+            model.zero_grad()
+            loss = model(input_ids=ids, labels=ids).loss
+            loss.backward()
+            outs.append((loss.detach().clone(), model.flat_grad.clone()))
+    finally:
+        mm._SPLIT_PROJ = saved
+    (l1, g1), (l0, g0) = outs
+    assert torch.equal(l1, l0), (float(l1), float(l0))
+    err = float((g1 - g0).abs().max() / g0.abs().max())
+    assert err < 1e-5, err
+    # and without gradients (evaluation / prefill use the same forward)
+    with torch.no_grad():
+        model.eval()
+        le = model(input_ids=ids, labels=ids).loss
+        model.train()
+    assert torch.equal(le, l1)
+
+
 def test_row_padding_changes_nothing(ops):
     """The 128 bytes of row padding that the training step gives qkv, the rotated q|k, the attention output and the
     gradient activations (pitches that would be multiples of 2 KiB) must not change a bit of the loss; gradients agree
