@@ -92,7 +92,7 @@ def bench_decode(model, cfg, streams, prompt_len, new_tokens, dev):
     N - 1 steps; algorithmic bytes per step = bf16 weights + the [streams, V] bf16 logits + the KV cache of the
     context, summed over the run's growing contexts. Reported per GPU, with a roofline block (bound: hbm)."""
     g = torch.Generator().manual_seed(99)
-    prompt = torch.randint(3, 30000, (streams, prompt_len), generator=g).to(dev)
+    prompt = torch.randint(3, min(30000, cfg.vocab_size), (streams, prompt_len), generator=g).to(dev)
     kw = dict(do_sample=True, temperature=0.97, top_k=0, top_p=0.95, seed=1234)
     # a serving process sizes its KV cache once: both timed runs below use it (same row capacity), and neither pays the
     # allocation and first-touch page faults of 60 GB of fresh device memory inside its first step

@@ -1,5 +1,6 @@
 """Decode-only benchmark (GPU box): bench.py's two decode legs without the training step.
    python tools/bench_decode.py [repeats]      env: MGEN_DECODE_PARTS, MGEN_GEMM_SKINNY, LEGS=literal,long,short;
+   MODEL=aria: the 650M Llama-style stand-in instead of the default decoder;
    GREEDY=1 replaces the sampler by the argmax (what the step costs without the top-p search and the draw)"""
 import os
 import sys
@@ -10,10 +11,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from mgen import MidiLM, default_decoder  # noqa: E402
+from mgen import MidiLM, default_decoder, aria_style_llama  # noqa: E402
 
 dev = torch.device("cuda:0")
-cfg = default_decoder()
+cfg = aria_style_llama() if os.environ.get("MODEL") == "aria" else default_decoder()
 model = MidiLM(cfg, device=dev, seed=0)
 if os.environ.get("GREEDY") == "1":
     _generate = model.generate
