@@ -354,14 +354,18 @@ int mgen_scale_f32(float* x, long n, float s, const float* a_dev, mgen_stream_t 
 int mgen_axpy_f32(float* y, const float* x, long n, float a, const float* a_dev, mgen_stream_t stream);
 int mgen_scale_bf16(void* x, long n, float a, const float* a_dev, mgen_stream_t stream);
 
-/* Projections of the one-token decode step (few token rows M, small weights): C[M, N] = A[M, K] W[N, K]^T in one
- * memory round trip per workgroup (64 x 64 x 512 tiles, all operand loads requested up front). slabs == 0: bf16
- * C [M][ldc], K == 512. slabs != 0: fp32 partial products of the K / 512 reduction slices, slab_stride elements apart
- * (summed by mgen_slab_resid_rmsnorm). a_swiglu != 0: A is gu [M][lda >= 2K] and the operand is silu(gate) * up
- * (Qwen3MLP.forward, TF models/qwen3/modeling_qwen3.py:81-83), formed while the tile is loaded.
+/* Projections of the one-token decode step (few token rows M, small weights): C[M, N] = A[M, K] W[N, K]^T with one
+ * memory round trip per 512 reduction indices and workgroup (32 x 64 x 512 tiles, all operand loads of a chunk
+ * requested up front; a workgroup small enough to share a CU with the attention kernel of another batch part).
+ * slabs == 0: bf16 C [M][ldc], the workgroup walks the whole reduction. slabs = s > 0 (s divides K / 512): s fp32
+ * partial products over K / s reduction indices each, slab_stride elements apart (summed by mgen_slab_resid_rmsnorm);
+ * mgen_gemm_skinny_slabs(M, N, K) is the count mgen_decode_layer uses (a workgroup for every CU, no more slabs than
+ * that needs). a_swiglu != 0: A is gu [M][lda >= 2K] and the operand is silu(gate) * up (Qwen3MLP.forward, TF
+ * models/qwen3/modeling_qwen3.py:81-83), formed while the tile is loaded.
  * mgen_gemm_skinny_fits returns 1 for the shapes the kernel takes (N % 64 == 0, K % 512 == 0, M <= 1024, ...).
  * Replaces the nn.Linear calls of a decoder layer at q_len = 1 (TF models/qwen3/modeling_qwen3.py:252-254, 279). */
 int mgen_gemm_skinny_fits(int M, int N, int K, long lda, long ldw, long ldc, int slabs);
+int mgen_gemm_skinny_slabs(int M, int N, int K);
 int mgen_gemm_bf16_skinny(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
                           int slabs, long slab_stride, int a_swiglu, mgen_stream_t stream);
 

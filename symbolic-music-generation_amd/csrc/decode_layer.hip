@@ -9,6 +9,7 @@
 #include "common.h"
 
 extern "C" int mgen_gemm_skinny_fits(int M, int N, int K, long lda, long ldw, long ldc, int slabs);
+extern "C" int mgen_gemm_skinny_slabs(int M, int N, int K);
 extern "C" int mgen_gemm_bf16_skinny(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw,
                                      long ldc, int slabs, long slab_stride, int a_swiglu, hipStream_t stream);
 extern "C" int mgen_attn_decode_prep(const void* qkv, long ld_in, const float* wq, const float* wk,
@@ -22,14 +23,17 @@ extern "C" int mgen_slab_resid_rmsnorm(const float* slabs, int nslabs, long slab
 // 1 when mgen_decode_layer takes these shapes (every projection on the few-row kernel)
 extern "C" int mgen_decode_layer_fits(int B, int d, int H, int KVH, int D, int I) {
     const int NQ = (H + 2 * KVH) * D, HD = H * D;
+    if (d < 64 || HD < 512 || I < 512) return 0;
     return mgen_gemm_skinny_fits(B, NQ, d, d, d, NQ, 0) && mgen_gemm_skinny_fits(B, 2 * I, d, d, d, 2 * I, 0) &&
-           mgen_gemm_skinny_fits(B, d, HD, HD, HD, d, 1) && mgen_gemm_skinny_fits(B, d, I, 2L * I, I, d, 1);
+           mgen_gemm_skinny_fits(B, d, HD, HD, HD, d, mgen_gemm_skinny_slabs(B, d, HD)) &&
+           mgen_gemm_skinny_fits(B, d, I, 2L * I, I, d, mgen_gemm_skinny_slabs(B, d, I));
 }
 
 // x      bf16 [B][d]   in: this layer's normed input; out: the NEXT norm's output (next layer's input / final norm)
 // h_in   fp32 [B][d]   residual stream entering the layer; h_mid, h_out fp32 [B][d] (h_out may be h_in's buffer of
 //                      the layer before: three buffers rotate)
-// qkv bf16 [B][(H+2KVH)D], att bf16 [B][H D], gu bf16 [B][2I], slabs fp32 [max(HD, I)/512][B][d]: scratch
+// qkv bf16 [B][(H+2KVH)D], att bf16 [B][H D], gu bf16 [B][2I]: scratch; slabs fp32 [n][B][d] with n = the larger of
+// mgen_gemm_skinny_slabs(B, d, HD) and mgen_gemm_skinny_slabs(B, d, I): scratch
 // weights: w_qkv [(H+2KVH)D][d], w_o [d][HD], w_gu [2I][d], w_down [d][I] bf16; gains fp32: w_qn, w_kn [D] (both may be
 // null), w_ln2 [d] (post-attention norm), w_next [d] (the norm that follows the layer)
 // pos[b] = position of the new token, kv_len[b] = pos[b] + 1; caches [B][KVH][max_len][D] bf16
@@ -51,11 +55,12 @@ extern "C" int mgen_decode_layer(void* x, const float* h_in, float* h_mid, float
     if (int e = mgen_attn_decode_prep(qkv, NQ, w_qn, w_kn, cos_sin, pos, eps, interleaved, k_cache, v_cache, kv_len, att,
                                       HD, attn_workspace, B, H, KVH, D, max_len, nsplit, scale, stream))
         return e;
-    if (int e = mgen_gemm_bf16_skinny(att, w_o, slabs, B, d, HD, HD, HD, d, 1, bd, 0, stream)) return e;
-    if (int e = mgen_slab_resid_rmsnorm(slabs, HD / 512, bd, h_in, h_mid, w_ln2, x, B, d, eps, 1, stream)) return e;
+    const int ns_o = mgen_gemm_skinny_slabs(B, d, HD), ns_d = mgen_gemm_skinny_slabs(B, d, I);
+    if (int e = mgen_gemm_bf16_skinny(att, w_o, slabs, B, d, HD, HD, HD, d, ns_o, bd, 0, stream)) return e;
+    if (int e = mgen_slab_resid_rmsnorm(slabs, ns_o, bd, h_in, h_mid, w_ln2, x, B, d, eps, 1, stream)) return e;
     if (int e = mgen_gemm_bf16_skinny(x, w_gu, gu, B, 2 * I, d, d, d, 2 * I, 0, 0, 0, stream)) return e;
-    if (int e = mgen_gemm_bf16_skinny(gu, w_down, slabs, B, d, I, 2L * I, I, d, 1, bd, 1, stream)) return e;
-    return mgen_slab_resid_rmsnorm(slabs, I / 512, bd, h_mid, h_out, w_next, x, B, d, eps, 1, stream);
+    if (int e = mgen_gemm_bf16_skinny(gu, w_down, slabs, B, d, I, 2L * I, I, d, ns_d, bd, 1, stream)) return e;
+    return mgen_slab_resid_rmsnorm(slabs, ns_d, bd, h_mid, h_out, w_next, x, B, d, eps, 1, stream);
 }
 
 namespace {

@@ -150,6 +150,8 @@ def lib():
         l.mgen_decode_layer_fits.restype = ctypes.c_int
         l.mgen_gemm_skinny_fits.argtypes = [I, I, I, L, L, L, I]
         l.mgen_gemm_skinny_fits.restype = ctypes.c_int
+        l.mgen_gemm_skinny_slabs.argtypes = [I, I, I]
+        l.mgen_gemm_skinny_slabs.restype = ctypes.c_int
         l.mgen_attn_decode_workspace.argtypes = [I, I, I, I]
         l.mgen_attn_decode_workspace.restype = ctypes.c_long
         l.mgen_device_info.argtypes = [I, ctypes.c_char_p, I]

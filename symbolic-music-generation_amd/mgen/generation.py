@@ -97,11 +97,11 @@ class _DecodeBuffers:
         sk = not cfg.pos4d
         self.sk_qkv = sk and ops.skinny_fits(B, NQ, d, d, d, NQ, False)
         self.sk_gu = sk and ops.skinny_fits(B, 2 * I, d, d, d, 2 * I, False)
-        self.sk_o = sk and ops.skinny_fits(B, d, HD, HD, HD, d, True)
-        self.sk_down = sk and ops.skinny_fits(B, d, I, 2 * I, I, d, True)
+        self.sk_o = sk and HD % 512 == 0 and ops.skinny_fits(B, d, HD, HD, HD, d, ops.skinny_slabs(B, d, HD))
+        self.sk_down = sk and I % 512 == 0 and ops.skinny_fits(B, d, I, 2 * I, I, d, ops.skinny_slabs(B, d, I))
         # split-K slabs of the two residual projections (K = H*Dh and K = I)
-        self.ns_o = HD // 512 if self.sk_o else ops.gemm_slab_count(HD)
-        self.ns_d = I // 512 if self.sk_down else ops.gemm_slab_count(I)
+        self.ns_o = ops.skinny_slabs(B, d, HD) if self.sk_o else ops.gemm_slab_count(HD)
+        self.ns_d = ops.skinny_slabs(B, d, I) if self.sk_down else ops.gemm_slab_count(I)
         self.slabs = torch.empty(max(self.ns_o, self.ns_d), B, d, dtype=f32, device=dev)
         self.layer_args = {}
         if cfg.pos4d:
@@ -185,7 +185,7 @@ class GenerationMixin:
         # The two residual projections have few output tiles at M = B rows: they run split along K into fp32 slabs,
         # and one kernel sums the slabs, adds the residual and applies the norm that follows.
         if buf.sk_o:
-            ops.linear_skinny(buf.att, v.s_o, buf.slabs, slabs=True)
+            ops.linear_skinny(buf.att, v.s_o, buf.slabs, slabs=buf.ns_o)
         else:
             ops.linear_slabs(buf.att, v.s_o, buf.slabs, buf.ns_o)
         self._slab_resid_norm(buf.slabs, buf.ns_o, h, buf.h1, v.w_ln2, v.w_ln2b, buf.x)
@@ -194,7 +194,7 @@ class GenerationMixin:
         else:
             ops.linear_fwd(buf.x, v.s_gu, buf.gu)
         if buf.sk_down:
-            ops.linear_skinny(buf.gu, v.s_down, buf.slabs, slabs=True, a_swiglu=True)
+            ops.linear_skinny(buf.gu, v.s_down, buf.slabs, slabs=buf.ns_d, a_swiglu=True)
         else:
             ops.swiglu_fwd(buf.gu, buf.act)
             ops.linear_slabs(buf.act, v.s_down, buf.slabs, buf.ns_d)

@@ -125,12 +125,21 @@ def skinny_fits(M, N, K, lda, ldw, ldc, slabs):
                                                                                                 int(slabs)))
 
 
-def linear_skinny(x, w, out, slabs=False, a_swiglu=False):
+def skinny_slabs(M, N, K):
+    """Number of fp32 slabs the library cuts a K-long reduction into for mgen_slab_resid_rmsnorm to sum."""
+    from ._lib import lib
+    return int(lib().mgen_gemm_skinny_slabs(M, N, K))
+
+
+def linear_skinny(x, w, out, slabs=0, a_swiglu=False):
     """Decode-step projection out = x @ w^T (x [M, K] bf16, or gu [M, 2K] with a_swiglu: the operand is
-    silu(gate) * up); out bf16 [M, N], or with slabs fp32 [K / 512, M, N] partial products."""
+    silu(gate) * up); out bf16 [M, N], or with slabs = s fp32 [s, M, N] partial products over K / s reduction indices
+    each (s divides K / 512; True = one per 512 indices)."""
     _need_gpu(x, w, out)
     M = x.shape[0]
     N, K = w.shape
+    if slabs is True:
+        slabs = K // 512
     call("mgen_gemm_bf16_skinny", _p(x), _p(w), _p(out), M, N, K, x.stride(0), w.stride(0), N, int(slabs),
          M * N, int(a_swiglu), _stream())
 

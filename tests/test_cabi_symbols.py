@@ -29,7 +29,7 @@ def test_ctypes_table_matches_header():
     from mgen import _lib
     declared = set(header_functions())
     bound = set(_lib.SIGNATURES) | {"mgen_last_error", "mgen_version", "mgen_source_id", "mgen_sumsq_partial_count", "mgen_device_info",
-                                     "mgen_attn_decode_workspace", "mgen_gemm_slab_count", "mgen_gemm_skinny_fits", "mgen_lmhead_ce_workspace_bytes", "mgen_decode_layer_fits"}
+                                     "mgen_attn_decode_workspace", "mgen_gemm_slab_count", "mgen_gemm_skinny_fits", "mgen_gemm_skinny_slabs", "mgen_lmhead_ce_workspace_bytes", "mgen_decode_layer_fits"}
     assert declared == bound, (declared - bound, bound - declared)
 
 

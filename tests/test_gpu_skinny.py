@@ -67,9 +67,53 @@ def test_gated_operand(ops, M):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 4608, 1536), (256, 1024, 2048), (37, 12288, 1536)])
+def test_bf16_output_over_several_chunks(ops, M, N, K):
+    """A reduction longer than 512 with a bf16 output: the workgroup walks its chunks in ascending order (the 650M
+    model's QKV and gate/up projections); same bits as the tile-loop kernel."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(dev())
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev())
+    assert ops.skinny_fits(M, N, K, K, K, N, 0)
+    out = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=dev())
+    ops.linear_skinny(x, w, out[:M])
+    ref = x.float() @ w.float().t()
+    assert float((out[:M].float() - ref).abs().max() / ref.abs().max()) < 1e-2
+    assert bool((out[M] == 7.0).all()), "wrote past the M rows"
+    old = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.linear_fwd(x, w, old)
+    assert torch.equal(old, out[:M])
+
+
+@pytest.mark.parametrize("M,N,K,gated", [(128, 1536, 6144, True), (128, 1536, 1536, False), (256, 512, 2048, True)])
+def test_fewer_slabs_than_chunks(ops, M, N, K, gated):
+    """Slabs that cover several 512-index chunks each (the count mgen_gemm_skinny_slabs picks, and every other
+    divisor): each slab against fp32 arithmetic on its reduction range; the gated operand as with one chunk per slab."""
+    g = torch.Generator().manual_seed(M + N + K)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev())
+    if gated:
+        gu = (torch.randn(M, 2 * K, generator=g)).to(torch.bfloat16).to(dev())
+        x = torch.empty(M, K, dtype=torch.bfloat16, device=dev())
+        ops.swiglu_fwd(gu, x)
+    else:
+        x = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(dev())
+    chunks = K // 512
+    picked = ops.skinny_slabs(M, N, K)
+    assert chunks % picked == 0 and (picked == chunks or ((M + 31) // 32) * (N // 64) * picked >= 256)
+    for ns in sorted({picked} | {s for s in range(1, chunks + 1) if chunks % s == 0}):
+        assert ops.skinny_fits(M, N, K, 2 * K if gated else K, K, N, ns)
+        slabs = torch.full((ns + 1, M, N), 7.0, dtype=torch.float32, device=dev())
+        ops.linear_skinny(gu if gated else x, w, slabs, slabs=ns, a_swiglu=gated)
+        assert bool((slabs[ns] == 7.0).all())
+        per = K // ns
+        for z in range(ns):
+            ref = x[:, z * per:(z + 1) * per].float() @ w[:, z * per:(z + 1) * per].float().t()
+            assert float((slabs[z] - ref).abs().max() / ref.abs().max()) < 1e-5, (ns, z)
+
+
 def test_shapes_not_taken(ops):
     from mgen._lib import MgenError
-    assert not ops.skinny_fits(256, 3072, 1536, 1536, 1536, 3072, False)   # bf16 output needs K == 512
+    assert not ops.skinny_fits(256, 3072, 1536, 1536, 1536, 3072, 2)       # 2 slabs do not divide 3 chunks
     assert not ops.skinny_fits(256, 1000, 512, 512, 512, 1000, False)      # N % 64
     assert not ops.skinny_fits(4096, 512, 512, 512, 512, 512, False)       # too many rows
     x = torch.zeros(8, 768, dtype=torch.bfloat16, device=dev())

@@ -1,4 +1,4 @@
-"""Time the decode attention kernel alone (GPU box only): 256 streams x 8 heads x head_dim 128, bf16 K/V cache rows.
+"""Time the decode attention kernel alone (GPU box only): 256 streams x 8 heads x head_dim 128 (HEADS=H,KVH,D for another shape), bf16 K/V cache rows.
 Arguments: context length(s); MAXLEN=<n> sets the cache's row capacity (the pitch between streams)."""
 import os
 import sys
@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
 from mgen import ops  # noqa: E402
 
-B, H, KVH, D = int(os.environ.get("STREAMS", "256")), 8, 8, 128
+B = int(os.environ.get("STREAMS", "256"))
+H, KVH, D = (int(x) for x in os.environ.get("HEADS", "8,8,128").split(","))   # HEADS=24,24,64: the 650M model
 dev = "cuda"
 lens = [int(a) for a in sys.argv[1:]] or [1920]
 for max_len in [int(x) for x in os.environ.get("MAXLEN", "2048").split(",")]:

@@ -18,12 +18,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(streams=256, prompt_len=1792, new_tokens=33):
     sys.path.insert(0, os.path.join(ROOT, "symbolic-music-generation_amd"))
     import torch
-    from mgen import MidiLM, default_decoder
+    from mgen import MidiLM, default_decoder, aria_style_llama
     dev = torch.device("cuda:0")
-    cfg = default_decoder()
+    cfg = aria_style_llama() if os.environ.get("MODEL") == "aria" else default_decoder()   # MODEL=aria: the 650M model
     model = MidiLM(cfg, device=dev, seed=0)
     g = torch.Generator().manual_seed(99)
-    prompt = torch.randint(3, 30000, (streams, prompt_len), generator=g).to(dev)
+    prompt = torch.randint(3, min(30000, cfg.vocab_size), (streams, prompt_len), generator=g).to(dev)
     out = model.generate(prompt, max_new_tokens=new_tokens, do_sample=True, temperature=0.97, top_k=0, top_p=0.95,
                          seed=1234)
     torch.cuda.synchronize()
