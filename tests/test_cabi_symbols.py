@@ -74,3 +74,27 @@ def test_library_was_built_from_the_sources_beside_it():
     if not os.environ.get("MGEN_LIB"):
         with pytest.raises(_lib.MgenError, match="other sources"):
             _lib._check_source_id(Stale)
+
+
+def test_few_row_projection_shape_rules_need_no_gpu():
+    """Host-side shape rules of the decode-step projections: the slab count gives every CU of a 256-CU chip a
+    workgroup with as few slabs as that takes and always divides the number of 512-index chunks; the layer call takes
+    the default decoder and the 650M model at 128 streams."""
+    from mgen import _lib
+    l = _lib.lib()
+    for M, N, K in [(128, 512, 1024), (128, 512, 2048), (128, 1536, 1536), (128, 1536, 6144), (256, 512, 2048),
+                    (1, 512, 1024), (1000, 1536, 6144)]:
+        s = l.mgen_gemm_skinny_slabs(M, N, K)
+        chunks = K // 512
+        tiles = ((M + 31) // 32) * (N // 64)
+        assert 1 <= s <= chunks and chunks % s == 0
+        assert s == chunks or tiles * s >= 256
+        assert all(tiles * d < 256 for d in range(1, s) if chunks % d == 0)
+        assert l.mgen_gemm_skinny_fits(M, N, K, K, K, N, s) == 1
+    assert l.mgen_gemm_skinny_slabs(128, 512, 1024) == 2 and l.mgen_gemm_skinny_slabs(128, 512, 2048) == 4
+    assert l.mgen_gemm_skinny_slabs(128, 1536, 1536) == 3 and l.mgen_gemm_skinny_slabs(128, 1536, 6144) == 3
+    assert l.mgen_gemm_skinny_fits(128, 4608, 1536, 1536, 1536, 4608, 0) == 1    # bf16 output over three chunks
+    assert l.mgen_gemm_skinny_fits(128, 512, 1536, 1536, 1536, 512, 2) == 0      # 2 slabs do not divide 3 chunks
+    assert l.mgen_decode_layer_fits(128, 512, 8, 8, 128, 2048) == 1
+    assert l.mgen_decode_layer_fits(128, 1536, 24, 24, 64, 6144) == 1
+    assert l.mgen_decode_layer_fits(128, 512, 8, 8, 128, 2000) == 0
